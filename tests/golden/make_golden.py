@@ -1,0 +1,199 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself on CPU.
+
+Runs only in the authoring container (needs /root/reference).  Nothing of the reference is
+copied: the script imports it, loads the build's own synthesised weights
+(interflow_amd/synth.py, key-compatible with the reference, `load_state_dict(strict=True)`),
+feeds seeded synthetic inputs and stores inputs (when small) and outputs as .npz.
+
+The reference's `utils/util.py` imports natsort, cv2 and torchvision at module level although the
+flow path only uses `opt_get`; none is installed here, so empty placeholder modules are
+registered for those three names before the import.  `.cuda()` calls in
+`flow_model.py` (lines 147,152,160,213) are made identity for the CPU run.
+
+usage: python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/interflow"
+
+from interflow_amd import synth  # noqa: E402
+
+
+def import_reference():
+    for name in ("natsort", "cv2", "torchvision", "torchvision.utils"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.path.insert(0, REF)
+    from models.flow_model import InterpFlow   # noqa
+    import models.modules.flow as rflow        # noqa
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    return InterpFlow, rflow
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def main():
+    torch.manual_seed(0)
+    np.random.seed(0)
+    torch.set_num_threads(8)
+    InterpFlow, rflow = import_reference()
+    scales = [2, 4]
+    sd_np = synth.synth_interpflow_state(scales, seed=0)
+    model = InterpFlow(scales=scales)
+    ref_sd = model.state_dict()
+    keys = {k: list(v.shape) for k, v in ref_sd.items()}
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    missing = set(keys) - set(sd_np)
+    extra = set(sd_np) - set(keys)
+    assert not missing and not extra, (sorted(missing)[:5], sorted(extra)[:5])
+    model.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+    model.eval()
+    digest = synth.state_digest(sd_np)
+    fu = model.flow_upsampler
+
+    with torch.no_grad():
+        # ------------------------------------------------------------------ per-op fixtures
+        ops = {}
+        rng = np.random.default_rng(1234)
+
+        def rnd(*shape, s=1.0):
+            return (rng.standard_normal(shape) * s).astype(np.float32)
+
+        x = rnd(2, 3, 6, 10)
+        ops["sq_in"] = x
+        ops["sq_out"] = rflow.squeeze2d(t(x), 2).numpy()
+        ops["sq2_out"] = rflow.squeeze2d(rflow.squeeze2d(t(x[:, :, :4, :8]), 2), 2).numpy()
+        y = rnd(2, 48, 3, 5)
+        ops["unsq_in"] = y
+        ops["unsq_out"] = rflow.unsqueeze2d(t(y), 2).numpy()
+        ops["sq4_out"] = rflow.squeeze2d(t(x[:, :, :4, :8]), 4).numpy()
+
+        for tag, li, hw in (("c12", 3, (6, 10)), ("c48", 22, (5, 7)), ("c12n", 1, (3, 9)), ("c48n", 21, (4, 4))):
+            step = fu.layers[li]
+            C = step.actnorm.bias.shape[1]
+            zin = rnd(2, C, *hw)
+            ld0 = rnd(2)
+            ops[f"{tag}_layer"] = np.array(li)
+            ops[f"{tag}_z"] = zin
+            ops[f"{tag}_ld"] = ld0
+            a, lda = step.actnorm(t(zin), logdet=t(ld0), reverse=False)
+            ops[f"{tag}_an_fwd"], ops[f"{tag}_an_fwd_ld"] = a.numpy(), lda.numpy()
+            a, lda = step.actnorm(t(zin), logdet=t(ld0), reverse=True)
+            ops[f"{tag}_an_rev"], ops[f"{tag}_an_rev_ld"] = a.numpy(), lda.numpy()
+            a, lda = step.invconv(t(zin), t(ld0), False)
+            ops[f"{tag}_ic_fwd"], ops[f"{tag}_ic_fwd_ld"] = a.numpy(), lda.numpy()
+            a, lda = step.invconv(t(zin), t(ld0), True)
+            ops[f"{tag}_ic_rev"], ops[f"{tag}_ic_rev_ld"] = a.numpy(), lda.numpy()
+            ops[f"{tag}_ic_w_fwd"] = step.invconv.get_weight(t(zin), False)[0].numpy().reshape(C, C)
+            ops[f"{tag}_ic_w_rev"] = step.invconv.get_weight(t(zin), True)[0].numpy().reshape(C, C)
+            ft = rnd(2, 320, *hw)
+            ops[f"{tag}_ft"] = ft
+            if hasattr(step, "affine"):
+                a, lda = step.affine(t(zin), logdet=t(ld0), reverse=False, ft=t(ft))
+                ops[f"{tag}_cp_enc"], ops[f"{tag}_cp_enc_ld"] = a.numpy(), lda.numpy()
+                a, lda = step.affine(t(zin), logdet=t(ld0), reverse=True, ft=t(ft))
+                ops[f"{tag}_cp_dec"], ops[f"{tag}_cp_dec_ld"] = a.numpy(), lda.numpy()
+                h = step.affine.fFeatures(t(ft))
+                ops[f"{tag}_fFeatures"] = h.numpy()
+                h = step.affine.fAffine(torch.cat([t(zin)[:, :C // 2], t(ft)], 1))
+                ops[f"{tag}_fAffine"] = h.numpy()
+            a, lda = step(t(zin), t(ld0), reverse=False, rrdbResults=t(ft))
+            ops[f"{tag}_step_enc"], ops[f"{tag}_step_enc_ld"] = a.numpy(), lda.numpy()
+            a, lda = step(t(zin), t(ld0), reverse=True, rrdbResults=t(ft))
+            ops[f"{tag}_step_dec"], ops[f"{tag}_step_dec_ld"] = a.numpy(), lda.numpy()
+
+        # Gaussian prior (flow.py:138-161) and the loss head (flow_model.py:119-173,202-215)
+        zz = rnd(4, 48, 5, 6, s=1.3)
+        ops["g_z"] = zz
+        ops["g_std"] = rflow.Gaussian.logp(None, None, t(zz)).numpy()
+        cov = t(sd_np["cov_shift_1"]) @ t(sd_np["cov_shift_1"]).T
+        mean = t(sd_np["mean_shift_1"]) * torch.ones(48)
+        ops["g_shift"] = rflow.Gaussian.logp(mean, cov, t(zz)).numpy()
+        ld = rnd(4, s=100.0)
+        label = torch.tensor([2, 4, 4, 2])
+        _, nll, _, ll_ib = model.calculate_loss(t(zz), t(ld), 20 * 24, label)
+        ops["loss_ld"], ops["loss_label"] = ld, label.numpy()
+        ops["loss_nll"], ops["loss_ll_ib"] = nll.numpy(), ll_ib.numpy()
+        ops["pdf"] = model.get_pdf(t(zz), [2, 4]).numpy()
+        ops["digest"] = np.array(digest)
+        np.savez_compressed(os.path.join(HERE, "ops_seed0.npz"), **ops)
+
+        # ------------------------------------------------------------------ whole stack, 32x32, synthetic features
+        st = {}
+        B, H = 2, 32
+        xin = synth.synth_images(11, B, H, H)
+        feats = {k: t(v) for k, v in synth.synth_features(12, B, H, H).items()}
+        for tis in (None, H):
+            tag = "tisNone" if tis is None else "tis"
+            z, ld = fu(gt=t(xin), rrdbResults=feats, logdet=torch.zeros(B), reverse=False,
+                       y_onehot=torch.zeros(B), test_input_size=tis)
+            xr, ldr = fu(z=z, rrdbResults=feats, logdet=torch.zeros(B), reverse=True,
+                         y_onehot=torch.zeros(B), test_input_size=tis)
+            st[f"{tag}_z"], st[f"{tag}_ld"] = z.numpy(), ld.numpy()
+            st[f"{tag}_xr"], st[f"{tag}_ldr"] = xr.numpy(), ldr.numpy()
+        # odd, non-square size (multiple of 4): 20 x 36
+        xin2 = synth.synth_images(13, 1, 20, 36)
+        feats2 = {k: t(v) for k, v in synth.synth_features(14, 1, 20, 36).items()}
+        z, ld = fu(gt=t(xin2), rrdbResults=feats2, logdet=torch.zeros(1), reverse=False, y_onehot=torch.zeros(1))
+        xr, ldr = fu(z=z, rrdbResults=feats2, logdet=torch.zeros(1), reverse=True, y_onehot=torch.zeros(1))
+        st["odd_z"], st["odd_ld"], st["odd_xr"], st["odd_ldr"] = z.numpy(), ld.numpy(), xr.numpy(), ldr.numpy()
+        st["digest"] = np.array(digest)
+        np.savez_compressed(os.path.join(HERE, "stack32_seed0.npz"), **st)
+
+        # ------------------------------------------------------------------ full size 160x160, synthetic features
+        fs = {}
+        B, H = 2, 160
+        xin = synth.synth_images(1, B, H, H)
+        feats = {k: t(v) for k, v in synth.synth_features(2, B, H, H).items()}
+        z, ld = fu(gt=t(xin), rrdbResults=feats, logdet=torch.zeros(B), reverse=False, y_onehot=torch.zeros(B))
+        xr, ldr = fu(z=z, rrdbResults=feats, logdet=torch.zeros(B), reverse=True, y_onehot=torch.zeros(B))
+        print("full: z std %.3f  |x-xr|max %.3e  ld %s ldr %s" % (z.std().item(), (xr - t(xin)).abs().max().item(),
+                                                                 ld.numpy(), ldr.numpy()))
+        fs["z"], fs["ld"], fs["xr"], fs["ldr"] = z.numpy(), ld.numpy(), xr.numpy(), ldr.numpy()
+        fs["digest"] = np.array(digest)
+        np.savez_compressed(os.path.join(HERE, "full160_seed0.npz"), **fs)
+
+        # ------------------------------------------------------------------ InterpFlow API incl. RRDB encoder, 64x64
+        api = {}
+        B, H = 2, 64
+        gt = synth.synth_images(21, B, H, H)
+        lr2 = synth.synth_images(22, B, H, H)
+        lr4 = synth.synth_images(23, B, H, H)
+        lr_enc = model.arch.rrdbPreprocessing(t(gt))
+        for k in ("fea_up1", "fea_up2", "fea_up4"):
+            api["enc_" + k + "_sum"] = lr_enc[k].double().sum().numpy()
+            api["enc_" + k + "_abs"] = lr_enc[k].double().abs().sum().numpy()
+        api["enc_fea_up1"] = lr_enc["fea_up1"].numpy()
+        label = torch.tensor([2, 4])
+        z, nll, ld, ll_ib = model(t(lr2), t(gt), label, lr_enc=lr_enc, add_gt_noise=False)
+        api["z"], api["nll"], api["ld"], api["ll_ib"] = z.numpy(), nll.numpy(), ld.numpy(), ll_ib.numpy()
+        z2, ld2 = model(t(lr4), t(gt), add_gt_noise=False, calc_loss=False)
+        api["z2"], api["ld2"] = z2.numpy(), ld2.numpy()
+        xr, ldr = model(z, t(gt), reverse=True, add_gt_noise=True, test_input_size=H, lr_enc=lr_enc)
+        api["xr_noise_ld"] = ldr.numpy()
+        out = model.weighted_interpolate_image(t(lr2), t(lr4), 0.35, cond_gt=t(gt))
+        api["wi_035"] = out.numpy()
+        out = model.interpolate_image(t(lr2), 2, t(lr4), 4, 2.6, cond_gt=t(gt))
+        api["interp_26"] = out.numpy()
+        api["digest"] = np.array(digest)
+        np.savez_compressed(os.path.join(HERE, "api64_seed0.npz"), **api)
+    for fn in sorted(os.listdir(HERE)):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)))
+
+
+if __name__ == "__main__":
+    main()

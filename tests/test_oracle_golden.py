@@ -1,0 +1,151 @@
+"""Pins the CPU oracle (oracle/interflow_oracle.py) to fixtures produced by the imported
+reference (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from interflow_amd import synth
+from oracle import interflow_oracle as O
+
+SCALES = [2, 4]
+
+
+@pytest.fixture(scope="module")
+def sd_np():
+    return synth.synth_interpflow_state(SCALES, seed=0)
+
+
+@pytest.fixture(scope="module")
+def sd(sd_np):
+    return O.to_torch(sd_np)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_state_keys_and_digest(golden_dir, sd_np):
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    assert set(keys) == set(sd_np)
+    for k, shp in keys.items():
+        assert list(sd_np[k].shape) == shp, k
+    assert len(keys) == 3078            # SURVEY.md section 5 "Checkpoint"
+    g = _load(golden_dir, "ops_seed0.npz")
+    assert str(g["digest"]) == synth.state_digest(sd_np), "synthesised weights differ from the fixture's"
+
+
+def test_squeeze_bit_exact(golden_dir):
+    g = _load(golden_dir, "ops_seed0.npz")
+    x = t(g["sq_in"])
+    assert np.array_equal(O.squeeze2d(x, 2).numpy(), g["sq_out"])
+    assert np.array_equal(O.squeeze2d(O.squeeze2d(x[:, :, :4, :8], 2), 2).numpy(), g["sq2_out"])
+    assert np.array_equal(O.squeeze2d(x[:, :, :4, :8], 4).numpy(), g["sq4_out"])
+    assert np.array_equal(O.unsqueeze2d(t(g["unsq_in"]), 2).numpy(), g["unsq_out"])
+    assert np.array_equal(O.unsqueeze2d(O.squeeze2d(x, 2), 2).numpy(), g["sq_in"])
+
+
+@pytest.mark.parametrize("tag", ["c12", "c48", "c12n", "c48n"])
+def test_step_ops(golden_dir, sd, tag):
+    g = _load(golden_dir, "ops_seed0.npz")
+    li = int(g[f"{tag}_layer"])
+    p = f"flow_upsampler.layers.{li}."
+    z, ld, ft = t(g[f"{tag}_z"]), t(g[f"{tag}_ld"]), t(g[f"{tag}_ft"])
+    for rev, nm in ((False, "fwd"), (True, "rev")):
+        a, l = O.actnorm(z, sd[p + "actnorm.bias"], sd[p + "actnorm.logs"], ld, rev)
+        close(a, g[f"{tag}_an_{nm}"]); close(l, g[f"{tag}_an_{nm}_ld"])
+        a, l = O._invconv_from_sd(z, ld, rev, sd, p + "invconv.")
+        close(a, g[f"{tag}_ic_{nm}"]); close(l, g[f"{tag}_ic_{nm}_ld"])
+        w = O.invconv_weight(*(sd[p + "invconv." + k] for k in ("p", "l", "u", "log_s", "sign_s")), rev)
+        close(w, g[f"{tag}_ic_w_{nm}"], 1e-6, 1e-6)
+    if f"{tag}_cp_enc" in g:
+        C = z.shape[1]
+        close(O.coupling_nn(ft, sd, p + "affine.fFeatures."), g[f"{tag}_fFeatures"])
+        close(O.coupling_nn(torch.cat([z[:, :C // 2], ft], 1), sd, p + "affine.fAffine."), g[f"{tag}_fAffine"])
+        a, l = O.cond_affine_separated_and_cond(z, ld, False, ft, sd, p + "affine.")
+        close(a, g[f"{tag}_cp_enc"]); close(l, g[f"{tag}_cp_enc_ld"], 1e-5, 1e-4)
+        a, l = O.cond_affine_separated_and_cond(z, ld, True, ft, sd, p + "affine.")
+        close(a, g[f"{tag}_cp_dec"]); close(l, g[f"{tag}_cp_dec_ld"], 1e-5, 1e-4)
+    a, l = O.flow_step(z, ld, False, ft, sd, p)
+    close(a, g[f"{tag}_step_enc"]); close(l, g[f"{tag}_step_enc_ld"], 1e-5, 1e-4)
+    a, l = O.flow_step(z, ld, True, ft, sd, p)
+    close(a, g[f"{tag}_step_dec"]); close(l, g[f"{tag}_step_dec_ld"], 1e-5, 1e-4)
+
+
+def test_gaussian_and_loss(golden_dir, sd):
+    g = _load(golden_dir, "ops_seed0.npz")
+    z = t(g["g_z"])
+    close(O.gaussian_logp(None, None, z), g["g_std"], 1e-6, 1e-3)
+    cov = sd["cov_shift_1"] @ sd["cov_shift_1"].T
+    mean = sd["mean_shift_1"] * torch.ones(48)
+    close(O.gaussian_logp(mean, cov, z), g["g_shift"], 1e-6, 1e-3)
+    ms = [sd["mean_shift_0"], sd["mean_shift_1"]]
+    cs = [sd["cov_shift_0"], sd["cov_shift_1"]]
+    _, nll, _, ll_ib = O.calculate_loss(z, t(g["loss_ld"]), 20 * 24, t(g["loss_label"]), SCALES, ms, cs)
+    close(nll, g["loss_nll"], 1e-6, 1e-6); close(ll_ib, g["loss_ll_ib"], 1e-5, 1e-6)
+    close(O.get_pdf(z, [2, 4], SCALES, ms, cs), g["pdf"], 1e-6, 1e-6)
+
+
+def test_stack32(golden_dir, sd):
+    g = _load(golden_dir, "stack32_seed0.npz")
+    B, H = 2, 32
+    x = t(synth.synth_images(11, B, H, H))
+    feats = {k: t(v) for k, v in synth.synth_features(12, B, H, H).items()}
+    for tis, tag in ((None, "tisNone"), (H, "tis")):
+        z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B), tis)
+        close(z, g[f"{tag}_z"], 1e-4, 1e-4); close(ld, g[f"{tag}_ld"], 1e-5, 1e-2)
+        xr, ldr = O.flow_decode(t(g[f"{tag}_z"]), feats, sd, "flow_upsampler.", torch.zeros(B), tis)
+        close(xr, g[f"{tag}_xr"], 1e-4, 1e-4); close(ldr, g[f"{tag}_ldr"], 1e-5, 1e-2)
+    x = t(synth.synth_images(13, 1, 20, 36))
+    feats = {k: t(v) for k, v in synth.synth_features(14, 1, 20, 36).items()}
+    z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(1))
+    close(z, g["odd_z"], 1e-4, 1e-4); close(ld, g["odd_ld"], 1e-5, 1e-2)
+    xr, ldr = O.flow_decode(t(g["odd_z"]), feats, sd, "flow_upsampler.", torch.zeros(1))
+    close(xr, g["odd_xr"], 1e-4, 1e-4); close(ldr, g["odd_ldr"], 1e-5, 1e-2)
+
+
+def test_api64_with_encoder(golden_dir, sd):
+    g = _load(golden_dir, "api64_seed0.npz")
+    B, H = 2, 64
+    gt, lr2, lr4 = (t(synth.synth_images(s, B, H, H)) for s in (21, 22, 23))
+    lr_enc = O.rrdb_preprocessing(gt, sd, "arch.RRDB.")
+    close(lr_enc["fea_up1"], g["enc_fea_up1"], 1e-5, 1e-5)
+    for k in ("fea_up1", "fea_up2", "fea_up4"):
+        assert abs(lr_enc[k].double().abs().sum().item() / float(g["enc_" + k + "_abs"]) - 1) < 1e-6
+    z, ld = O.interpflow_forward(sd, lr2, lr_enc=lr_enc)
+    close(z, g["z"], 1e-4, 1e-4); close(ld, g["ld"], 1e-5, 1e-2)
+    ms = [sd["mean_shift_0"], sd["mean_shift_1"]]
+    cs = [sd["cov_shift_0"], sd["cov_shift_1"]]
+    _, nll, _, ll_ib = O.calculate_loss(z, ld, H * H, torch.tensor([2, 4]), SCALES, ms, cs)
+    close(nll, g["nll"], 1e-5, 1e-5); close(ll_ib, g["ll_ib"], 1e-4, 1e-5)
+    _, ldr = O.interpflow_forward(sd, t(g["z"]), cond=gt, lr_enc=lr_enc, reverse=True, test_input_size=H,
+                                  add_gt_noise=True)
+    close(ldr, g["xr_noise_ld"], 1e-5, 1e-2)
+    out = O.weighted_interpolate(sd, lr2, lr4, 0.35, lr_enc)
+    close(out, g["wi_035"], 1e-4, 1e-4)
+    a = (2.6 - 4.0) / (2.0 - 4.0)          # flow_model.py:189: a*z1 + (1-a)*z2
+    out = O.weighted_interpolate(sd, lr4, lr2, a, lr_enc)
+    close(out, g["interp_26"], 1e-4, 1e-4)
+
+
+@pytest.mark.slow
+def test_full160(golden_dir, sd):
+    g = _load(golden_dir, "full160_seed0.npz")
+    B, H = 2, 160
+    x = t(synth.synth_images(1, B, H, H))
+    feats = {k: t(v) for k, v in synth.synth_features(2, B, H, H).items()}
+    z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B))
+    close(z, g["z"], 1e-4, 2e-4); close(ld, g["ld"], 1e-6, 0)
+    xr, ldr = O.flow_decode(t(g["z"]), feats, sd, "flow_upsampler.", torch.zeros(B))
+    close(xr, g["xr"], 1e-4, 1e-4); close(ldr, g["ldr"], 1e-6, 0)
