@@ -1,0 +1,125 @@
+/*
+ * interflow_hip.h -- C ABI of libinterflow_hip.so: the MI355X (gfx950) implementation of
+ * InterFlow's conditional normalizing-flow forward / inverse pass.
+ *
+ * The reference (dongjinkim9/InterFlow) is pure PyTorch: it has no FFI for this path.  The
+ * boundary it exposes is the Python operator
+ *   FlowUpsamplerNet.forward(gt, rrdbResults, z, epses, logdet, reverse, ...)   (interflow/models/modules/FlowUpsamplerNet.py:202-215)
+ * called from InterpFlow.forward (interflow/models/flow_model.py:83-116).  The entry points below
+ * are what a ctypes binding of that operator calls; each one cites the reference code it
+ * replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer except `layers` is DEVICE memory owned by the caller; nothing is allocated
+ *     or freed inside the library; all work is enqueued on `stream` and nothing synchronises.
+ *   - tensors at the boundary are contiguous NCHW float32, exactly as the reference passes them.
+ *   - every function returns 0 on success, a negative IFL_E* code on a rejected argument, or a
+ *     positive hipError_t; ifl_last_error() gives the text for the calling thread.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef INTERFLOW_HIP_H
+#define INTERFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFL_VERSION 1
+
+#define IFL_EINVAL   (-1)   /* bad shape / argument (the reference would raise AssertionError) */
+#define IFL_ENOTSUP  (-2)   /* configuration outside the shipped model (C not in {12,48}, ...)   */
+#define IFL_ESMALLWS (-3)   /* workspace smaller than ifl_ws_bytes() says                        */
+
+#define IFL_HIDDEN   64     /* coupling-network width, FlowAffineCouplingsAblation.py:133        */
+#define IFL_FT_CH    320    /* conditioning channels, FlowUpsamplerNet.py:117-120                */
+#define IFL_MAX_LEVELS 2    /* flow levels (squeezes), flow_model.py:42 L=2                      */
+
+/* One entry of FlowUpsamplerNet.layers (FlowUpsamplerNet.py:94-105). */
+typedef struct ifl_layer {
+    int32_t kind;        /* 0 = SqueezeLayer, 1 = FlowStep without coupling, 2 = conditional FlowStep */
+    int32_t C;           /* channels of the tensor this layer outputs (12 or 48)                     */
+    int64_t param_off;   /* offset, in floats, of this layer's block inside `params`                 */
+    float   sum_logs;    /* ActNorm: sum_c logs[c]        (FlowActNorms.py:72)                       */
+    float   sum_log_s;   /* InvertibleConv1x1: sum_c log_s[c] (Permutations.py:94)                   */
+} ifl_layer;
+
+int         ifl_version(void);
+const char* ifl_last_error(void);
+
+/* ---- packed parameter block of one FlowStep (layout documented in DESIGN.md section "params") ----
+ * ifl_step_param_floats: size in floats of the block for a step with C channels.
+ * ifl_step_field_off:    float offset of a field inside the block, field ids IFL_F_*.          */
+enum {
+    IFL_F_ANIC_FWD = 0,  /* [b(C)] [exp(logs)(C)] [W(CxC)]          ActNorm then 1x1 conv           */
+    IFL_F_ANIC_INV = 1,  /* [b(C)] [exp(-logs)(C)] [Winv(CxC)]      inverse 1x1 conv then ActNorm   */
+    IFL_F_W1A = 2, IFL_F_W1F = 3,    /* first 3x3 conv, MFMA A-fragment order                       */
+    IFL_F_AN1A = 4, IFL_F_AN1F = 5,  /* its ActNorm (bias, exp(logs)) in accumulator order          */
+    IFL_F_W2A = 6, IFL_F_W2F = 7,    /* 1x1 conv                                                    */
+    IFL_F_AN2A = 8, IFL_F_AN2F = 9,
+    IFL_F_W3A = 10, IFL_F_W3F = 11,  /* Conv2dZeros 3x3, rows grouped as (shift,shift,scale,scale)  */
+    IFL_F_B3A = 12, IFL_F_B3F = 13,  /* its bias and exp(3*logs) per accumulator element            */
+    IFL_F_COUNT = 14
+};
+int64_t ifl_step_param_floats(int C, int has_coupling);
+int64_t ifl_step_field_off(int C, int field);
+
+/* ---- workspace ----
+ * One workspace serves every call with the same (B, H, W).  It holds the zero-ringed
+ * channels-last copies of the conditioning features, the running z of each level, the hidden
+ * activations of the coupling networks and the per-tile log-det partial sums.
+ * ifl_ws_init must run once after allocation (and again if the memory was reused for another
+ * shape): it zeroes the padding rings the kernels rely on.  ifl_ws_bytes returns the size in
+ * bytes, or a negative IFL_E* code for a shape the library rejects.                            */
+int64_t ifl_ws_bytes(int B, int H, int W);
+int     ifl_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, void* stream);
+
+/* Copy the conditioning feature map of one flow level (level 1: H/2 x W/2, level 2: H/4 x W/4;
+ * NCHW [B,320,h,w]) into the workspace.  Replaces the per-layer
+ * `rrdbResults[self.levelToName[level]]` lookups of FlowUpsamplerNet.py:236-239,278-280; the
+ * caller applies the reference's level rule and passes the tensor it selects.                   */
+int ifl_load_cond(void* ws, int B, int H, int W, int level, const float* ft_nchw, void* stream);
+
+/* FlowUpsamplerNet.encode (FlowUpsamplerNet.py:217-255): x [B,3,H,W] -> z [B,48,H/4,W/4],
+ * logdet_out[b] = logdet_in[b] + sum of the layers' log-determinants.  H, W multiples of 4
+ * (flow.py:172).  eps = CondAffineSeparatedAndCond 'eps' (flow_model.py:46).                    */
+int ifl_flow_encode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
+                    const float* x, float* z, const float* logdet_in, float* logdet_out,
+                    int B, int H, int W, float eps, void* stream);
+
+/* FlowUpsamplerNet.decode (FlowUpsamplerNet.py:271-304): z [B,48,H/4,W/4] -> x [B,3,H,W].      */
+int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
+                    const float* z, float* x, const float* logdet_in, float* logdet_out,
+                    int B, int H, int W, float eps, void* stream);
+
+/* ---- stand-alone operators on NCHW tensors ---- */
+/* squeeze2d / unsqueeze2d, flow.py:163-193 (pure index permutation, bit-exact). */
+int ifl_squeeze2d(const float* in, float* out, int B, int C, int H, int W, int factor, void* stream);
+int ifl_unsqueeze2d(const float* in, float* out, int B, int C, int H, int W, int factor, void* stream);
+
+/* One FlowStep on NCHW tensors (FlowStep.py:114-196): z_in [B,C,h,w] -> z_out, logdet updated.
+ * ft [B,320,h,w] is read only when the step has a coupling.  Uses `ws` sized by
+ * ifl_ws_bytes(B, 2h, 2w) for C = 12 or ifl_ws_bytes(B, 4h, 4w) for C = 48 (it runs the step on
+ * the workspace's level-1 / level-2 buffers).                                                    */
+int ifl_flow_step(const ifl_layer* layer, const float* params, void* ws, const float* z_in,
+                  float* z_out, const float* ft, const float* logdet_in, float* logdet_out,
+                  int B, int h, int w, int reverse, float eps, void* stream);
+
+/* Gaussian.logp, flow.py:138-161: out[b] = sum_{h,w} -1/2 (logdet_cov + k ln 2pi + (x-mean)^T cov_inv (x-mean)).
+ * cov_inv = NULL means the standard normal (mean ignored, logdet_cov = 0).  k = C <= 64.
+ * scratch: B*ifl_logp_scratch_floats(H*W) floats.                                               */
+int64_t ifl_logp_scratch_floats(int HW);
+int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov,
+                      float* scratch, float* out, int B, int C, int H, int W, void* stream);
+
+/* Latent interpolation z = wa[b]*za + wb[b]*zb (flow_model.py:186-200, train.py:88-92).
+ * wa/wb are per-sample weights in device memory, n_per_sample = C*H*W.                          */
+int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,
+             int B, int64_t n_per_sample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTERFLOW_HIP_H */

@@ -1,0 +1,140 @@
+// Internal definitions shared by the kernels and the C ABI of libinterflow_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/interflow_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define IFL_FT 320            // conditioning channels
+#define IFL_HID 64            // coupling-network hidden width
+#define IFL_H2 128            // hidden buffer channels: [fAffine 64 | fFeatures 64]
+#define IFL_MT 128            // pixels per workgroup tile of the two conv kernels
+#define IFL_PP_MAX 304        // max patch pixels (tile + 1-pixel halo) a workgroup stages in LDS
+#define IFL_CK 32             // channels per LDS chunk
+#define IFL_CS 36             // LDS pixel stride (words) of a 32-channel chunk: CS/4 odd => b128 conflict-free
+#define IFL_CS3 40            // same for the 16x16x4 reads of conv3
+
+static inline __host__ __device__ int ifl_roundup(int a, int b) { return (a + b - 1) / b * b; }
+static inline __host__ __device__ int ifl_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- tiling of one level's H x W image plane into workgroup tiles ---------------------------------
+// The plane is cut into vertical bands of width bw; inside a band pixels are enumerated in raster
+// order and cut into chunks of IFL_MT consecutive pixels.  A tile's LDS patch is the rows it touches
+// plus one halo row above/below and one halo column left/right.
+struct IflGeom {
+    int H, W;             // plane size of this level
+    int bw;               // band width (last band may be narrower)
+    int nbands;
+    int tiles_per_band;   // ceil(H*bw / IFL_MT)
+    int ntiles;           // nbands * tiles_per_band   (= gridDim.x)
+};
+
+struct IflTile {          // decoded per workgroup (all fields wave-uniform)
+    int x0, bwb;          // band origin / width
+    int s, npx;           // first pixel index of the chunk inside the band, pixels in the band
+    int y_first;          // first patch row in image coordinates (may be -1)
+    int nrows, PW, PP;    // patch rows, patch width (bwb+2), patch pixels
+    bool active;
+};
+
+static inline __host__ __device__ IflTile ifl_tile(const IflGeom& g, int tile) {
+    IflTile t;
+    int band = tile / g.tiles_per_band, chunk = tile - band * g.tiles_per_band;
+    t.x0 = band * g.bw;
+    t.bwb = g.W - t.x0 < g.bw ? g.W - t.x0 : g.bw;
+    t.npx = g.H * t.bwb;
+    t.s = chunk * IFL_MT;
+    t.active = t.s < t.npx;
+    int e = t.s + IFL_MT < t.npx ? t.s + IFL_MT : t.npx;
+    int r0 = t.s / t.bwb, r1 = (e - 1) / t.bwb;
+    t.y_first = r0 - 1;
+    t.nrows = r1 - r0 + 3;
+    t.PW = t.bwb + 2;
+    t.PP = t.nrows * t.PW;
+    return t;
+}
+
+// ---- per-step packed parameter layout (floats) ----------------------------------------------------
+static inline __host__ __device__ int ifl_kz(int C) { return ifl_roundup(C / 2, 8); }       // z1 channels fed to fAffine, padded
+static inline __host__ __device__ int ifl_nf(int C) { return ifl_cdiv(C, 8); }              // 16-row output tiles of fFeatures' last conv
+static inline __host__ __device__ int ifl_na(int C) { return ifl_cdiv(C / 2, 8); }          // same for fAffine
+
+struct IflStepOff {       // float offsets inside one step's block
+    int64_t anic_fwd, anic_inv;
+    int64_t w1[2], an1[2], w2[2], an2[2], w3[2], b3[2];     // [0] = fAffine, [1] = fFeatures
+    int64_t total;
+};
+
+static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_coupling) {
+    IflStepOff o;
+    int64_t p = 0;
+    auto take = [&](int64_t n) { int64_t r = p; p += (n + 63) / 64 * 64; return r; };   // 256-byte aligned fields
+    o.anic_fwd = take(2 * C + C * C);
+    o.anic_inv = take(2 * C + C * C);
+    for (int n = 0; n < 2; ++n) { o.w1[n] = o.an1[n] = o.w2[n] = o.an2[n] = o.w3[n] = o.b3[n] = 0; }
+    if (has_coupling) {
+        o.w1[0] = take((int64_t)IFL_HID * 9 * (IFL_FT + ifl_kz(C)));
+        o.w1[1] = take((int64_t)IFL_HID * 9 * IFL_FT);
+        for (int n = 0; n < 2; ++n) o.an1[n] = take(2 * IFL_HID);
+        for (int n = 0; n < 2; ++n) o.w2[n] = take(IFL_HID * IFL_HID);
+        for (int n = 0; n < 2; ++n) o.an2[n] = take(2 * IFL_HID);
+        o.w3[0] = take((int64_t)ifl_na(C) * 16 * 9 * IFL_HID);
+        o.w3[1] = take((int64_t)ifl_nf(C) * 16 * 9 * IFL_HID);
+        o.b3[0] = take(ifl_na(C) * 32);
+        o.b3[1] = take(ifl_nf(C) * 32);
+    }
+    o.total = p;
+    return o;
+}
+
+// ---- workspace layout -----------------------------------------------------------------------------
+struct IflLevelWs {
+    int H, W;                 // plane size at this level
+    int C;                    // z channels
+    float* ft;                // [B][H+2][W+2][320]  zero ring
+    float* z;                 // [B][H+2][W+2][C]    zero ring
+    float* h2;                // [B][H+2][W+2][128]  zero ring
+    IflGeom geom;
+};
+
+struct IflWs {
+    int B, H, W;
+    IflLevelWs lv[IFL_MAX_LEVELS];
+    float* ldpart;            // [B][ld_slots] per-tile log-det partial sums
+    int ld_slots;
+    int64_t bytes;
+};
+
+int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out);     // base may be NULL (size query)
+void ifl_set_error(const char* fmt, ...);
+
+#define IFL_CHECK_ARG(cond, code, ...) do { if (!(cond)) { ifl_set_error(__VA_ARGS__); return (code); } } while (0)
+#define IFL_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ifl_set_error("%s: %s", #call, hipGetErrorString(e_)); return (int)e_; } } while (0)
+#define IFL_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ifl_set_error("kernel launch: %s", hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------------
+// layout.hip
+int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);                 // NCHW -> ringed NHWC
+int ifl_k_ring_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);
+int ifl_k_squeeze_in(const float* x, float* zr, int B, int C, int H, int W, hipStream_t st);                     // NCHW [B,C,H,W] -> ringed NHWC [B,H/2,W/2,4C]
+int ifl_k_unsqueeze_out(const float* zr, float* x, int B, int C, int H, int W, hipStream_t st);                  // inverse
+int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hipStream_t st);                    // ringed [H,W,C] -> ringed [H/2,W/2,4C]
+int ifl_k_unsqueeze_ring(const float* b, float* a, int B, int C, int H, int W, hipStream_t st);
+int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, int f, int reverse, hipStream_t st);
+// pointwise.hip
+int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st);            // in place on ringed NHWC
+int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
+                      double constant, double sign, int B, hipStream_t st);
+int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* scratch,
+               float* out, int B, int C, int HW, hipStream_t st);
+int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B,
+               int64_t n, hipStream_t st);
+// conv1.hip:  nets: 0 = fAffine only, 1 = fFeatures only, 2 = both
+int ifl_k_conv1(const float* ft, const float* z, float* h2, const float* prm, const IflStepOff& off,
+                const IflGeom& g, int B, int C, int nets, hipStream_t st);
+// conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine
+int ifl_k_conv3(const float* h2, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
+                const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st);

@@ -1,0 +1,184 @@
+// layout.hip -- index permutations (bit-exact): squeeze / unsqueeze and the NCHW <-> ringed channels-last
+// conversions at the boundary of the fused flow.
+//
+//   squeeze2d / unsqueeze2d          reference interflow/models/modules/flow.py:163-193
+//       out[b, c*f*f + i*f + j, h, w] = in[b, c, h*f + i, w*f + j]
+//   "ringed NHWC": [B][H+2][W+2][C] float32 with a one-pixel ring of zeros -- the 3x3 convs of the coupling
+//   networks read their 'same' zero padding (flow.py:27) from the ring instead of testing bounds.
+#include "ifl_common.h"
+
+namespace {
+
+// ---- NCHW [B,C,P=H*W] -> ringed NHWC, 32x32 tile transpose through LDS ------------------------------------------
+__global__ __launch_bounds__(256)
+void nchw_to_ring_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W)
+{
+    __shared__ float tile[32][33];
+    const int P = H * W;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int i = threadIdx.x & 31, jj = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = c0 + jj + 8 * k, p = p0 + i;
+        tile[jj + 8 * k][i] = (c < C && p < P) ? in[((int64_t)b * C + c) * P + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int p = p0 + jj + 8 * k, c = c0 + i;
+        if (p < P && c < C) {
+            int y = p / W, x = p - y * W;
+            out[(((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = tile[i][jj + 8 * k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void ring_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W)
+{
+    __shared__ float tile[32][33];
+    const int P = H * W;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int i = threadIdx.x & 31, jj = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int p = p0 + jj + 8 * k, c = c0 + i;
+        float v = 0.f;
+        if (p < P && c < C) {
+            int y = p / W, x = p - y * W;
+            v = in[(((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c];
+        }
+        tile[jj + 8 * k][i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = c0 + jj + 8 * k, p = p0 + i;
+        if (c < C && p < P) out[((int64_t)b * C + c) * P + p] = tile[i][jj + 8 * k];
+    }
+}
+
+// ---- x NCHW [B,C,H,W] -> squeezed ringed NHWC [B][H/2+2][W/2+2][4C]; one thread per output pixel ------------------
+// out[b,h,w,4c+2i+j] = x[b,c,2h+i,2w+j]
+__global__ __launch_bounds__(256)
+void squeeze_in_kernel(const float* __restrict__ x, float* __restrict__ zr, int B, int C, int H, int W)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)B * Ho * Wo) return;
+    int w = p % Wo; int64_t t = p / Wo; int h = t % Ho; int b = t / Ho;
+    float* dst = zr + (((int64_t)b * (Ho + 2) + h + 1) * (Wo + 2) + w + 1) * (4 * C);
+    for (int c = 0; c < C; ++c) {
+        const float* src = x + (((int64_t)b * C + c) * H + 2 * h) * W + 2 * w;
+        f32x2 r0 = *(const f32x2*)src, r1 = *(const f32x2*)(src + W);
+        dst[4 * c + 0] = r0[0]; dst[4 * c + 1] = r0[1]; dst[4 * c + 2] = r1[0]; dst[4 * c + 3] = r1[1];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void unsqueeze_out_kernel(const float* __restrict__ zr, float* __restrict__ x, int B, int C, int H, int W)
+{
+    const int Ho = H / 2, Wo = W / 2;       // zr plane; x is [B,C,H,W]
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)B * Ho * Wo) return;
+    int w = p % Wo; int64_t t = p / Wo; int h = t % Ho; int b = t / Ho;
+    const float* src = zr + (((int64_t)b * (Ho + 2) + h + 1) * (Wo + 2) + w + 1) * (4 * C);
+    for (int c = 0; c < C; ++c) {
+        float* dst = x + (((int64_t)b * C + c) * H + 2 * h) * W + 2 * w;
+        *(f32x2*)dst = f32x2{src[4 * c + 0], src[4 * c + 1]};
+        *(f32x2*)(dst + W) = f32x2{src[4 * c + 2], src[4 * c + 3]};
+    }
+}
+
+// ---- ringed [H,W,C] <-> ringed [H/2,W/2,4C]; one thread per (output pixel, input channel) ------------------------
+__global__ __launch_bounds__(256)
+void squeeze_ring_kernel(const float* __restrict__ a, float* __restrict__ o, int B, int C, int H, int W, int reverse)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * Ho * Wo * C) return;
+    int c = e % C; int64_t t = e / C; int w = t % Wo; t /= Wo; int h = t % Ho; int b = t / Ho;
+    int64_t big = (((int64_t)b * (H + 2) + 2 * h + 1) * (W + 2) + 2 * w + 1) * C + c;       // pixel (2h, 2w) of the large plane
+    int64_t sml = ((((int64_t)b * (Ho + 2) + h + 1) * (Wo + 2) + w + 1) * C + c) * 4;       // channel 4c of the small plane
+    const int64_t row = (int64_t)(W + 2) * C;
+    if (!reverse) {
+        f32x4 v = {a[big], a[big + C], a[big + row], a[big + row + C]};
+        *(f32x4*)(o + sml) = v;
+    } else {      // a = small plane (input), o = large plane (output)
+        f32x4 v = *(const f32x4*)(a + sml);
+        o[big] = v[0]; o[big + C] = v[1]; o[big + row] = v[2]; o[big + row + C] = v[3];
+    }
+}
+
+// ---- stand-alone NCHW squeeze2d / unsqueeze2d (any factor); one thread per element of the squeezed tensor --------
+__global__ __launch_bounds__(256)
+void squeeze_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W, int f, int reverse)
+{
+    // squeezed tensor S [B, C*f*f, H/f, W/f]; large tensor L [B, C, H, W]
+    const int Ho = H / f, Wo = W / f;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * C * H * W) return;
+    int w = e % Wo; int64_t t = e / Wo; int h = t % Ho; t /= Ho; int cs = t % (C * f * f); int b = t / (C * f * f);
+    int c = cs / (f * f), ij = cs - c * f * f, i = ij / f, j = ij - i * f;
+    int64_t l = (((int64_t)b * C + c) * H + h * f + i) * W + w * f + j;
+    if (!reverse) out[e] = in[l]; else out[l] = in[e];
+}
+
+}  // namespace
+
+int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, hipStream_t st)
+{
+    dim3 grid(ifl_cdiv(H * W, 32), ifl_cdiv(C, 32), B);
+    hipLaunchKernelGGL(nchw_to_ring_kernel, grid, dim3(256), 0, st, in, out, C, H, W);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_ring_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st)
+{
+    dim3 grid(ifl_cdiv(H * W, 32), ifl_cdiv(C, 32), B);
+    hipLaunchKernelGGL(ring_to_nchw_kernel, grid, dim3(256), 0, st, in, out, C, H, W);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_squeeze_in(const float* x, float* zr, int B, int C, int H, int W, hipStream_t st)
+{
+    int64_t n = (int64_t)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(squeeze_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, zr, B, C, H, W);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_unsqueeze_out(const float* zr, float* x, int B, int C, int H, int W, hipStream_t st)
+{
+    int64_t n = (int64_t)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(unsqueeze_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, zr, x, B, C, H, W);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hipStream_t st)
+{
+    int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(squeeze_ring_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, B, C, H, W, 0);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_unsqueeze_ring(const float* b, float* a, int B, int C, int H, int W, hipStream_t st)
+{
+    int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(squeeze_ring_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, a, B, C, H, W, 1);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, int f, int reverse, hipStream_t st)
+{
+    int64_t n = (int64_t)B * C * H * W;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(squeeze_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, C, H, W, f, reverse);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,196 @@
+// pointwise.hip -- bandwidth-bound per-pixel kernels of the flow.
+//
+//   anic:  ActNorm2d fused with InvertibleConv1x1 (and the exact inverse pair)
+//          fwd  y = W * ((x + b) .* exp(logs))            FlowActNorms.py:87-92 then Permutations.py:114-118
+//          inv  x = (Winv * y) .* exp(-logs) - b          Permutations.py:119-123 then FlowActNorms.py:93-96
+//          W / Winv are built on the host exactly as Permutations.py:92-100 does (inverse in float64).
+//          The log-det terms (sum logs + sum log_s) * H*W are data independent and added by ld_finalize.
+//   ld_finalize: per-sample log-det = input + constant + sum of the couplings' per-tile partials (float64, fixed order)
+//   logp:  Gaussian.logp                                   flow.py:138-161
+//   lerp:  z = wa*za + wb*zb                               flow_model.py:186-200, train.py:88-92
+#include "ifl_common.h"
+
+namespace {
+
+// One thread per pixel of the ringed channels-last plane; W staged in LDS and read as broadcasts.
+template <int C>
+__global__ __launch_bounds__(256)
+void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse)
+{
+    __shared__ __attribute__((aligned(16))) float sw[C * C + 2 * C];
+    for (int i = threadIdx.x; i < C * C + 2 * C; i += 256) sw[i] = prm[i];
+    __syncthreads();
+    const float* sb = sw;            // bias
+    const float* ss = sw + C;        // exp(logs) or exp(-logs)
+    const float* wm = sw + 2 * C;    // W[co][ci] row-major
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)B * H * W) return;
+    int x = p % W; int64_t t = p / W; int y = t % H; int b = t / H;
+    float* px = zr + (((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C;
+    float v[C], o[C];
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+        f32x4 q = *(const f32x4*)(px + c);
+        v[c] = q[0]; v[c + 1] = q[1]; v[c + 2] = q[2]; v[c + 3] = q[3];
+    }
+    if (!inverse) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { v[c] = v[c] + sb[c]; v[c] = v[c] * ss[c]; }
+    }
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < C; ci += 4) {
+            f32x4 w = *(const f32x4*)(wm + co * C + ci);
+            acc = fmaf(w[0], v[ci], acc); acc = fmaf(w[1], v[ci + 1], acc);
+            acc = fmaf(w[2], v[ci + 2], acc); acc = fmaf(w[3], v[ci + 3], acc);
+        }
+        o[co] = acc;
+    }
+    if (inverse) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { o[c] = o[c] * ss[c]; o[c] = o[c] - sb[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *(f32x4*)(px + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
+}
+
+__global__ __launch_bounds__(64)
+void ld_finalize_kernel(const float* __restrict__ ldpart, int used, int ld_slots, const float* __restrict__ ld_in,
+                        float* __restrict__ ld_out, double constant)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int i = lane; i < used; i += 64) s += (double)ldpart[(int64_t)b * ld_slots + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) ld_out[b] = (float)((double)(ld_in ? ld_in[b] : 0.f) + constant + s);
+}
+
+// Gaussian log-density of every pixel's C-vector, summed over the pixels of a block -> scratch[b][block].
+// z is NCHW: lane = pixel, so every channel read is coalesced.  CT = compile-time C (registers) or 0 (any C <= 64,
+// re-reading z through the cache).
+constexpr int LOGP_PIX = 256;
+template <int CT>
+__global__ __launch_bounds__(256)
+void logp_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ cov_inv,
+                 float logdet_cov, float* __restrict__ scratch, int nblk, int Crt, int HW)
+{
+    __shared__ float sci[64 * 64 + 64];
+    __shared__ float red[4];
+    const int C = CT ? CT : Crt;
+    const int b = blockIdx.y;
+    if (cov_inv) {
+        for (int i = threadIdx.x; i < C * C; i += 256) sci[i] = cov_inv[i];
+        for (int i = threadIdx.x; i < C; i += 256) sci[64 * 64 + i] = mean[i];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * LOGP_PIX + threadIdx.x;
+    float lik = 0.f;
+    if (p < HW) {
+        const float* zp = z + (int64_t)b * C * HW + p;
+        float q = 0.f;
+        if (!cov_inv) {
+            for (int c = 0; c < C; ++c) { float v = zp[(int64_t)c * HW]; q = fmaf(v, v, q); }
+            logdet_cov = 0.f;
+        } else if (CT) {
+            float x[CT ? CT : 1];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) x[c] = zp[(int64_t)c * HW] - sci[64 * 64 + c];
+            // sum_c ( sum_k x[k] * cov_inv[k][c] ) * x[c]      (flow.py:156: (x @ cov_inv) * x)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < CT; ++k) t = fmaf(x[k], sci[k * CT + c], t);
+                q = fmaf(t, x[c], q);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                float t = 0.f;
+                for (int k = 0; k < C; ++k) t = fmaf(zp[(int64_t)k * HW] - sci[64 * 64 + k], sci[k * C + c], t);
+                q = fmaf(t, zp[(int64_t)c * HW] - sci[64 * 64 + c], q);
+            }
+        }
+        lik = -0.5f * (logdet_cov + (float)C * 1.8378770664093453f + q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lik += __shfl_xor(lik, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lik;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[(int64_t)b * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out = wa[b]*za + wb[b]*zb: two rounded products and one rounded sum, as torch evaluates (1-a)*z1 + a*z2
+__global__ __launch_bounds__(256)
+void lerp_kernel(const float* __restrict__ za, const float* __restrict__ zb, const float* __restrict__ wa,
+                 const float* __restrict__ wb, float* __restrict__ out, int64_t n, int vec)
+{
+    const int b = blockIdx.y;
+    const float a = wa[b], c = wb[b];
+    const int64_t base = (int64_t)b * n;
+    if (vec) {
+        const f32x4* pa = (const f32x4*)(za + base);
+        const f32x4* pb = (const f32x4*)(zb + base);
+        f32x4* po = (f32x4*)(out + base);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+            f32x4 u = pa[i], v = pb[i], r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __fadd_rn(__fmul_rn(a, u[e]), __fmul_rn(c, v[e]));
+            po[i] = r;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+            out[base + i] = __fadd_rn(__fmul_rn(a, za[base + i]), __fmul_rn(c, zb[base + i]));
+    }
+}
+
+}  // namespace
+
+int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st)
+{
+    int64_t n = (int64_t)B * H * W;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (C == 12) hipLaunchKernelGGL((anic_kernel<12>), grid, block, 0, st, zr, prm, B, H, W, inverse);
+    else if (C == 48) hipLaunchKernelGGL((anic_kernel<48>), grid, block, 0, st, zr, prm, B, H, W, inverse);
+    else { ifl_set_error("actnorm+invconv: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
+                      double constant, double /*sign*/, int B, hipStream_t st)
+{
+    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, ldpart, slots_used, ld_slots, ld_in, ld_out, constant);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* scratch,
+               float* out, int B, int C, int HW, hipStream_t st)
+{
+    int nblk = ifl_cdiv(HW, LOGP_PIX);
+    dim3 grid(nblk, B), block(256);
+    if (C == 48) hipLaunchKernelGGL((logp_kernel<48>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
+    else if (C == 12) hipLaunchKernelGGL((logp_kernel<12>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
+    else hipLaunchKernelGGL((logp_kernel<0>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
+    IFL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, scratch, nblk, nblk, (const float*)nullptr, out, 0.0);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int64_t ifl_logp_scratch_floats(int HW) { return ifl_cdiv(HW, LOGP_PIX); }
+
+int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B, int64_t n,
+               hipStream_t st)
+{
+    if (n == 0 || B == 0) return 0;
+    int vec = (n % 4 == 0) ? 1 : 0;     // per-sample rows stay 16-byte aligned only then
+    int64_t work = vec ? n / 4 : n;
+    int gx = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+    hipLaunchKernelGGL(lerp_kernel, dim3(gx, B), dim3(256), 0, st, za, zb, wa, wb, out, n, vec);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,328 @@
+"""Drop-in for the reference's model API (`interflow/models/flow_model.py`, `RRDBGlowNet_arch.py`,
+`RRDBNet_arch.py`): same constructor, attributes, method signatures, return values and state-dict keys.
+
+`InterpFlow.forward` / `interpolate_image` / `weighted_interpolate_image` / `calculate_loss` / `get_pdf`
+run the flow, the latent prior and the latent interpolation through libinterflow_hip.so.  The
+conditioning encoder (`RRDBNet`, outside the hot path: SURVEY.md section 8(f) row 1) runs on stock
+PyTorch-ROCm ops.
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .flow_modules import FlowUpsamplerNet, opt_get
+
+
+# ------------------------------------------------------------------------------------- conditioning encoder
+class ResidualDenseBlock_5C(nn.Module):
+    """RRDBNet_arch.py:9-29"""
+
+    def __init__(self, nf=64, gc=32, bias=True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(nf, gc, 3, 1, 1, bias=bias)
+        self.conv2 = nn.Conv2d(nf + gc, gc, 3, 1, 1, bias=bias)
+        self.conv3 = nn.Conv2d(nf + 2 * gc, gc, 3, 1, 1, bias=bias)
+        self.conv4 = nn.Conv2d(nf + 3 * gc, gc, 3, 1, 1, bias=bias)
+        self.conv5 = nn.Conv2d(nf + 4 * gc, nf, 3, 1, 1, bias=bias)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        for m in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):      # module_util.py:7-16, scale 0.1
+            nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in')
+            m.weight.data *= 0.1
+            m.bias.data.zero_()
+
+    def forward(self, x):
+        x1 = self.lrelu(self.conv1(x))
+        x2 = self.lrelu(self.conv2(torch.cat((x, x1), 1)))
+        x3 = self.lrelu(self.conv3(torch.cat((x, x1, x2), 1)))
+        x4 = self.lrelu(self.conv4(torch.cat((x, x1, x2, x3), 1)))
+        x5 = self.conv5(torch.cat((x, x1, x2, x3, x4), 1))
+        return x5 * 0.2 + x
+
+
+class RRDB(nn.Module):
+    """RRDBNet_arch.py:32-45"""
+
+    def __init__(self, nf, gc=32):
+        super().__init__()
+        self.RDB1 = ResidualDenseBlock_5C(nf, gc)
+        self.RDB2 = ResidualDenseBlock_5C(nf, gc)
+        self.RDB3 = ResidualDenseBlock_5C(nf, gc)
+
+    def forward(self, x):
+        return self.RDB3(self.RDB2(self.RDB1(x))) * 0.2 + x
+
+
+class RRDBNet(nn.Module):
+    """RRDBNet_arch.py:48-148 for scale 4."""
+
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32, scale=4, opt=None):
+        super().__init__()
+        self.opt = opt
+        self.scale = scale
+        if scale != 4:
+            raise NotImplementedError("only scale 4 is in the shipped config")
+        self.conv_first = nn.Conv2d(in_nc * 16, nf, 3, 1, 1, bias=True)
+        self.RRDB_trunk = nn.Sequential(*[RRDB(nf=nf, gc=gc) for _ in range(nb)])
+        self.trunk_conv = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.upconv1 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.upconv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.HRconv = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.conv_last = nn.Conv2d(nf, out_nc, 3, 1, 1, bias=True)
+
+    @staticmethod
+    def space2depth(x, block_size):
+        n, c, h, w = x.size()                                                         # :79-83
+        return F.unfold(x, block_size, stride=block_size).view(n, c * block_size ** 2, h // block_size, w // block_size)
+
+    def forward(self, x, get_steps=False):
+        x = self.space2depth(x, 4)
+        fea = self.conv_first(x)
+        block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []
+        block_results = {}
+        for idx, m in enumerate(self.RRDB_trunk.children()):
+            fea = m(fea)
+            if idx in block_idxs:
+                block_results["block_{}".format(idx)] = fea
+        last_lr_fea = fea + self.trunk_conv(fea)
+        # :77,105-109 -- the reference's LeakyReLU is inplace, so the tensors it returns under 'fea_up2' and
+        # 'fea_up4' hold the POST-activation values; reproduced here.
+        fea_up2 = F.leaky_relu(self.upconv1(F.interpolate(last_lr_fea, scale_factor=2, mode='nearest')), 0.2)
+        fea_up4 = F.leaky_relu(self.upconv2(F.interpolate(fea_up2, scale_factor=2, mode='nearest')), 0.2)
+        out = self.conv_last(F.leaky_relu(self.HRconv(fea_up4), 0.2))
+        results = {'last_lr_fea': last_lr_fea, 'fea_up1': last_lr_fea, 'fea_up2': fea_up2, 'fea_up4': fea_up4,
+                   'fea_up8': None, 'fea_up16': None, 'fea_up32': None, 'out': out}
+        if opt_get(self.opt, ['network_G', 'flow', 'fea_up0']) or False:
+            results['fea_up0'] = F.interpolate(last_lr_fea, scale_factor=1 / 2, mode='bilinear')
+        if opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False:
+            results['fea_up-1'] = F.interpolate(last_lr_fea, scale_factor=1 / 4, mode='bilinear')
+        if get_steps:
+            results.update(block_results)
+            return results
+        return out
+
+
+class RRDBGlowNet(nn.Module):
+    """RRDBGlowNet_arch.py:16-59,217-246.  The DeFlow-legacy normal_flow/reverse_flow (:81-214) are not called
+    by InterFlow's drivers and are not provided."""
+
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32, scale=4, K=None, opt=None, step=None):
+        super().__init__()
+        self.opt = opt
+        self.RRDB = RRDBNet(in_nc, out_nc, nf, nb, gc, scale, opt)
+        hidden_channels = opt_get(opt, ['network_G', 'flow', 'hidden_channels']) or 64
+        self.RRDB_training = True
+        self.flowUpsamplerNet = FlowUpsamplerNet((160, 160, 3), hidden_channels, K,
+                                                 flow_coupling=opt['network_G']['flow']['coupling'],
+                                                 LU_decomposed=opt_get(opt, ['network_G', 'flow', 'LU_decomposed'], False),
+                                                 opt=opt)
+        C = self.flowUpsamplerNet.C
+        self.I = nn.Parameter(torch.eye(C), requires_grad=False)
+        self.mean_shift = nn.Parameter(torch.zeros(C))
+        self.cov_shift = nn.Parameter(torch.eye(C) * opt_get(opt, ['network_G', 'flow', 'shift', 'std_init_shift'], 1.0))
+
+    def set_rrdb_training(self, trainable):
+        if self.RRDB_training != trainable:
+            for p in self.RRDB.parameters():
+                p.requires_grad = trainable
+            self.RRDB_training = trainable
+            return True
+        return False
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("RRDBGlowNet.forward (DeFlow legacy) is not used by InterFlow; call InterpFlow")
+
+    def rrdbPreprocessing(self, lr):
+        rrdbResults = self.RRDB(lr, get_steps=True)
+        block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []
+        if len(block_idxs) > 0:
+            concat = torch.cat([rrdbResults["block_{}".format(idx)] for idx in block_idxs], dim=1)
+            if opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'concat']) or False:
+                keys = ['last_lr_fea', 'fea_up1', 'fea_up2', 'fea_up4']
+                if 'fea_up0' in rrdbResults.keys():
+                    keys.append('fea_up0')
+                if 'fea_up-1' in rrdbResults.keys():
+                    keys.append('fea_up-1')
+                for k in keys:
+                    h, w = rrdbResults[k].shape[2], rrdbResults[k].shape[3]
+                    rrdbResults[k] = torch.cat([rrdbResults[k], F.interpolate(concat, (h, w))], dim=1)
+        return rrdbResults
+
+
+class DegradationNet(nn.Module):
+    """flow_model.py:13-35 -- instantiated by the reference (:56) and never called; kept for the state dict."""
+
+    def __init__(self, in_ch=320, out_ch=48, hidden_ch=64, L=3):
+        super().__init__()
+        layers = []
+        for i in range(L):
+            cin = in_ch if i == 0 else hidden_ch
+            cout = out_ch if i == L - 1 else (64 if i == 0 else hidden_ch)
+            layers += [nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=True)]
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.net(x) + 0.5
+
+
+# ------------------------------------------------------------------------------------- prior
+class Gaussian:
+    """flow.py:138-161 on the HIP path."""
+    Log2PI = float(np.log(2 * np.pi))
+
+    @staticmethod
+    def logp(mean, cov, x):
+        if mean is None and cov is None:
+            return hip.gaussian_logp(x)
+        # torch.inverse / torch.slogdet of the 48x48 covariance: tiny host-side linear algebra, as the reference
+        cov_c = cov.detach().to("cpu", torch.float32)
+        cov_inv = torch.inverse(cov_c)
+        logdet = float(torch.slogdet(cov_c)[1])
+        mean_t = mean.detach().to(device=x.device, dtype=torch.float32).reshape(-1)
+        if mean_t.numel() == 1:
+            mean_t = mean_t.expand(x.shape[1])
+        return hip.gaussian_logp(x, mean_t.contiguous(), cov_inv.to(x.device).contiguous(), logdet)
+
+
+# ------------------------------------------------------------------------------------- model API
+class InterpFlow(nn.Module):
+    """flow_model.py:37-224"""
+
+    def __init__(self, scales: list, mean_init: float = 0.001, std_init: float = 1.0):
+        super().__init__()
+        opt = {'scale': 4,
+               'network_G': {'in_nc': 3, 'out_nc': 3, 'nf': 64, 'nb': 23, 'upscale': 4, 'train_RRDB': True, 'scale': 4,
+                             'flow': {'K': 16, 'L': 2, 'noInitialInj': True, 'LU_decomposed': True,
+                                      'coupling': 'CondAffineSeparatedAndCond', 'additionalFlowNoAffine': 2,
+                                      'split': {'enable': True}, 'fea_up0': True,
+                                      'stackRRDB': {'blocks': [1, 8, 15, 22], 'concat': True},
+                                      'CondAffineSeparatedAndCond': {'eps': 0.001, 'multReverse': True}}}, }
+        self.scale = 4
+        self.arch = RRDBGlowNet(in_nc=3, out_nc=3, nf=64, nb=23, scale=self.scale, K=16, opt=opt, step=0)
+        self.flow_upsampler = self.arch.flowUpsamplerNet
+        self.rrdb = self.arch.RRDB
+        self.degradation_net = DegradationNet()
+        self.quant = 256
+        self.classes = scales
+        self.C = self.flow_upsampler.C
+        self.I = nn.Parameter(torch.eye(self.C), requires_grad=False)
+        num_class = len(self.classes)
+        mean_interval = torch.linspace(-mean_init * (num_class // 2), mean_init * (num_class // 2), num_class)
+        self.mean_shifts = [nn.Parameter(torch.zeros(1) + mean_interval[i]) for i in range(num_class)]
+        self.cov_shifts = [nn.Parameter(torch.eye(self.C) * std_init) for _ in range(num_class)]
+        for i, p in enumerate(self.mean_shifts):
+            self.register_parameter(f"mean_shift_{i}", p)
+        for i, p in enumerate(self.cov_shifts):
+            self.register_parameter(f"cov_shift_{i}", p)
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda() replace Parameter objects' data in place, so the python lists stay valid; refresh anyway
+        r = super()._apply(fn, *a, **k)
+        self.mean_shifts = [getattr(self, f"mean_shift_{i}") for i in range(len(self.classes))]
+        self.cov_shifts = [getattr(self, f"cov_shift_{i}") for i in range(len(self.classes))]
+        return r
+
+    def forward(self, input_value, cond_image, label=None, reverse=False, test_input_size=None, lr_enc=None,
+                add_gt_noise=True, calc_loss=True):
+        if reverse:
+            if input_value is None:
+                raise NotImplementedError
+            lr, z = cond_image, input_value
+            if lr_enc is None:
+                lr_enc = self.arch.rrdbPreprocessing(lr)
+            logdet = torch.zeros_like(lr[:, 0, 0, 0])
+            if add_gt_noise:
+                pixels = int(lr.size(2) * lr.size(3))
+                logdet = logdet - float(-np.log(self.quant) * pixels)
+            return self.flow_upsampler(rrdbResults=lr_enc, z=z, logdet=logdet, reverse=True, epses=None,
+                                       y_onehot=None, test_input_size=test_input_size)
+        lr, gt = cond_image, input_value
+        logdet = torch.zeros_like(gt[:, 0, 0, 0])
+        pixels = int(gt.size(2) * gt.size(3))
+        if lr_enc is None:
+            lr_enc = self.arch.rrdbPreprocessing(lr)
+        if add_gt_noise:
+            gt = gt + ((torch.rand(gt.shape, device=gt.device) - 0.5) / self.quant)
+            logdet = logdet + float(-np.log(self.quant) * pixels)
+        z, logdet = self.flow_upsampler(rrdbResults=lr_enc, gt=gt, logdet=logdet, reverse=False, epses=None,
+                                        y_onehot=None)
+        if not calc_loss:
+            return z, logdet
+        return self.calculate_loss(z, logdet, pixels, label)
+
+    def _shifted(self, device):
+        covs = [torch.matmul(c, c.T) for c in self.cov_shifts]
+        means = [m * torch.ones(self.C, device=m.device) for m in self.mean_shifts]
+        return means, covs
+
+    def calculate_loss(self, epses, logdet, pixels, label):
+        objective = logdet.clone()
+        z = epses[-1] if isinstance(epses, (list, tuple)) else epses
+        if type(label) != torch.Tensor:
+            label = torch.Tensor(label)
+        assert z.shape[0] == label.shape[0], 'need one class label per datapoint'
+        assert len(label.shape) == 1, 'labels must be one dimensional'
+        label = label.to(z.device)
+        means, covs = self._shifted(z.device)
+        # log-density of every sample under every class prior: one HIP pass per class (flow_model.py:156-160)
+        ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
+        ll = torch.zeros(z.shape[0], device=z.device)
+        is_x = label == 0
+        if bool(is_x.any()):
+            ll = torch.where(is_x, Gaussian.logp(None, None, z), ll)
+        classes = torch.tensor(np.tile(self.classes, reps=z.shape[0]).reshape((z.shape[0], -1)), device=z.device)
+        mask_label = (classes == label.reshape(-1, 1))
+        ll = ll + (ll_all * mask_label).sum(dim=1)
+        ll_ib = ll_all / float(pixels)
+        ll_ib = torch.log_softmax(ll_ib, dim=1)
+        ll_ib = torch.masked_select(ll_ib, mask_label)
+        objective = objective + ll
+        nll = (-objective) / float(np.log(2.) * pixels)
+        if isinstance(epses, list):
+            return epses, nll, logdet
+        return z, nll, logdet, ll_ib
+
+    def get_lr(self, input_lr, heat=1., test_input_size=None):
+        z_shape = (input_lr.shape[0], input_lr.shape[1] * 16, input_lr.shape[2], input_lr.shape[3])
+        z = torch.normal(mean=0, std=heat, size=z_shape).to(input_lr.device)
+        return self.forward(z, input_lr, reverse=True, test_input_size=test_input_size)[0]
+
+    def interpolate_image(self, input_lr1, scale1, input_lr2, scale2, target_scale, cond_gt):
+        scale1 = torch.tensor(scale1).double()
+        scale2 = torch.tensor(scale2).double()
+        target_scale = torch.tensor(target_scale).double()
+        lr_enc = self.arch.rrdbPreprocessing(cond_gt)          # computed once, the reference recomputes it 3 times
+        z1, _ = self.forward(input_lr1, cond_gt, lr_enc=lr_enc, calc_loss=False)
+        z2, _ = self.forward(input_lr2, cond_gt, lr_enc=lr_enc, calc_loss=False)
+        a = (target_scale - scale2) / (scale1 - scale2)
+        target_z = hip.lerp(z1, z2, float(a), float(1 - a))
+        return self.forward(target_z, cond_gt, reverse=True, test_input_size=input_lr1.shape[2], lr_enc=lr_enc,
+                            calc_loss=False)[0]
+
+    def weighted_interpolate_image(self, input_lr1, input_lr2, a, cond_gt, add_noise=False):
+        lr_enc = self.arch.rrdbPreprocessing(cond_gt)
+        z1, _ = self.forward(input_lr1, cond_gt, lr_enc=lr_enc, add_gt_noise=add_noise, calc_loss=False)
+        z2, _ = self.forward(input_lr2, cond_gt, lr_enc=lr_enc, add_gt_noise=add_noise, calc_loss=False)
+        target_z = hip.lerp(z1, z2, 1 - a, a)
+        return self.forward(target_z, cond_gt, reverse=True, add_gt_noise=add_noise, lr_enc=lr_enc,
+                            test_input_size=input_lr1.shape[2], calc_loss=False)[0]
+
+    def get_pdf(self, z: torch.Tensor, scales: list):
+        pixels = int(z.size(2) * z.size(3))
+        means, covs = self._shifted(z.device)
+        ll = []
+        for scale in scales:
+            index = self.classes.index(scale)
+            ll.append(Gaussian.logp(means[index], covs[index], z) / float(np.log(2.) * pixels))
+        return torch.stack(ll, dim=0).reshape(-1)
+
+    def get_shifted_info(self):
+        if len(self.mean_shifts) != 0:
+            return np.stack([m.detach().cpu() for m in self.mean_shifts], axis=0), \
+                np.stack([c.detach().cpu() for c in self.cov_shifts], axis=0), self.classes
+        return None, None, None

@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's flow modules (`interflow/models/modules/*.py`).
+
+Same class names, constructor arguments, parameter/buffer names and call signatures as the reference,
+so `state_dict()` / `load_state_dict(strict=True)` interchange with it.  The modules only HOLD
+parameters; the arithmetic of the hot path runs in libinterflow_hip.so:
+
+* `FlowUpsamplerNet.forward` -> `ifl_flow_encode` / `ifl_flow_decode` (whole 38-layer stack natively);
+* `FlowStep.forward`         -> `ifl_flow_step`;
+* `SqueezeLayer.forward`     -> `ifl_squeeze2d` / `ifl_unsqueeze2d`.
+
+Leaf modules that the reference calls one by one (ActNorm2d, InvertibleConv1x1, Conv2d, ...) are fused
+into those kernels and have no forward of their own here.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip, pack
+from .synth import HIDDEN, N_RRDB_CH
+
+
+def opt_get(opt, keys, default=None):
+    """utils/util.py:259-267"""
+    if opt is None:
+        return default
+    ret = opt
+    for k in keys:
+        ret = ret.get(k, None)
+        if ret is None:
+            return default
+    return ret
+
+
+class _Fused(nn.Module):
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            f"{type(self).__name__} is fused into the FlowStep / FlowUpsamplerNet HIP kernels; call those")
+
+
+class ActNorm2d(_Fused):
+    """FlowActNorms.py:7-109 (parameter holder)."""
+
+    def __init__(self, num_features, scale=1.):
+        super().__init__()
+        self.register_parameter("bias", nn.Parameter(torch.zeros(1, num_features, 1, 1)))
+        self.register_parameter("logs", nn.Parameter(torch.zeros(1, num_features, 1, 1)))
+        self.num_features = num_features
+        self.scale = float(scale)
+        self.inited = False
+
+
+class InvertibleConv1x1(_Fused):
+    """Permutations.py:44-123 (parameter holder; same initialisation)."""
+
+    def __init__(self, num_channels, LU_decomposed=False, min_singular=None):
+        super().__init__()
+        import scipy.linalg
+        w_shape = [num_channels, num_channels]
+        w_init = np.linalg.qr(np.random.randn(*w_shape))[0].astype(np.float32)
+        if not LU_decomposed:
+            self.register_parameter("weight", nn.Parameter(torch.Tensor(w_init)))
+        else:
+            np_p, np_l, np_u = scipy.linalg.lu(w_init)
+            np_s = np.diag(np_u)
+            self.register_buffer('p', torch.Tensor(np_p.astype(np.float32)))
+            self.register_buffer('sign_s', torch.Tensor(np.sign(np_s).astype(np.float32)))
+            self.l = nn.Parameter(torch.Tensor(np_l.astype(np.float32)))
+            self.log_s = nn.Parameter(torch.Tensor(np.log(np.abs(np_s)).astype(np.float32)))
+            self.u = nn.Parameter(torch.Tensor(np.triu(np_u, k=1).astype(np.float32)))
+        self.w_shape = w_shape
+        self.LU = LU_decomposed
+        if min_singular is not None:
+            raise NotImplementedError("min_singular clipping (Permutations.py:108-111) is not part of the shipped config")
+
+
+class Conv2d(_Fused):
+    """flow.py:25-64: 3x3 / 1x1 'same' conv without bias + ActNorm (parameter holder)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), weight_std=0.05):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *kernel_size).normal_(0.0, weight_std))
+        self.actnorm = ActNorm2d(out_channels)
+
+
+class Conv2dZeros(_Fused):
+    """flow.py:67-82 (parameter holder)."""
+
+    def __init__(self, in_channels, out_channels, logscale_factor=3):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.logscale_factor = logscale_factor
+        self.register_parameter("logs", nn.Parameter(torch.zeros(out_channels, 1, 1)))
+
+
+def _F(in_channels, out_channels, hidden_channels):
+    """FlowAffineCouplingsAblation.py:248-256 -- indices 0, 2, 4 hold parameters (1, 3 are ReLUs)."""
+    return nn.Sequential(Conv2d(in_channels, hidden_channels), nn.ReLU(inplace=False),
+                         Conv2d(hidden_channels, hidden_channels, kernel_size=(1, 1)), nn.ReLU(inplace=False),
+                         Conv2dZeros(hidden_channels, out_channels))
+
+
+class CondAffineSeparatedAndCond(_Fused):
+    """FlowAffineCouplingsAblation.py:123-157 (parameter holder)."""
+
+    def __init__(self, in_channels, opt):
+        super().__init__()
+        self.need_features = True
+        self.in_channels = in_channels
+        self.in_channels_rrdb = N_RRDB_CH
+        key = ['network_G', 'flow', 'CondAffineSeparatedAndCond']
+        hidden = opt_get(opt, key + ['hidden_channels'])
+        self.hidden_channels = HIDDEN if hidden is None else hidden
+        self.affine_eps = opt_get(opt, key + ['eps'], 0.0001)
+        self.mult_reverse = opt_get(opt, key + ['multReverse'], False)
+        for flag in ('tanh', 'skip'):
+            if opt_get(opt, key + [flag], False):
+                raise NotImplementedError(f"CondAffineSeparatedAndCond option '{flag}' is outside the shipped config")
+        if self.hidden_channels != HIDDEN or not self.mult_reverse:
+            raise NotImplementedError("the HIP kernels implement hidden_channels=64, multReverse=True (flow_model.py:46)")
+        self.channels_for_nn = in_channels // 2
+        self.channels_for_co = in_channels - self.channels_for_nn
+        self.fAffine = _F(self.channels_for_nn + self.in_channels_rrdb, self.channels_for_co * 2, self.hidden_channels)
+        self.fFeatures = _F(self.in_channels_rrdb, in_channels * 2, self.hidden_channels)
+
+
+class SqueezeLayer(nn.Module):
+    """flow.py:196-207"""
+
+    def __init__(self, factor):
+        super().__init__()
+        self.factor = factor
+
+    def forward(self, input, logdet=None, reverse=False):
+        if not reverse:
+            return hip.squeeze2d(input, self.factor), logdet
+        return hip.unsqueeze2d(input, self.factor), logdet
+
+
+def _module_params_numpy(module, prefix=""):
+    return {prefix + k: v.detach().to("cpu", torch.float32).numpy() for k, v in module.state_dict().items()}
+
+
+def _version_key(module):
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
+class FlowStep(nn.Module):
+    """FlowStep.py:29-196: actnorm -> invconv -> coupling, and the exact reverse order."""
+
+    def __init__(self, in_channels, hidden_channels, actnorm_scale=1.0, flow_permutation="invconv",
+                 flow_coupling="additive", LU_decomposed=False, opt=None, idx=None, acOpt=None, normOpt=None,
+                 position=None):
+        super().__init__()
+        if flow_permutation != "invconv" or normOpt:
+            raise NotImplementedError("only flow_permutation='invconv' with ActNorm2d is in the shipped config")
+        if flow_coupling not in ("noCoupling", "CondAffineSeparatedAndCond"):
+            raise NotImplementedError(f"coupling '{flow_coupling}' is not reachable from the shipped config "
+                                      "(SURVEY.md section 2, row 11)")
+        self.flow_permutation = flow_permutation
+        self.flow_coupling = flow_coupling
+        self.position = position
+        self.in_channels = in_channels
+        self.actnorm = ActNorm2d(in_channels, actnorm_scale)
+        self.invconv = InvertibleConv1x1(in_channels, LU_decomposed=LU_decomposed)
+        if flow_coupling == "CondAffineSeparatedAndCond":
+            self.affine = CondAffineSeparatedAndCond(in_channels=in_channels, opt=opt)
+        self._packed = None
+
+    def _pack(self, device):
+        key = (_version_key(self), str(device), self.training)
+        if self._packed is None or self._packed[0] != key:
+            prm = _module_params_numpy(self, "layers.0.")
+            has = hasattr(self, "affine")
+            params, layers = pack.pack_flow(prm, [("stepc" if has else "step0", self.in_channels)],
+                                            training=self.training)
+            self._packed = (key, torch.from_numpy(params).to(device), layers)
+        return self._packed[1], self._packed[2]
+
+    def forward(self, input, logdet=None, reverse=False, rrdbResults=None):
+        z = hip._dev_f32(input, "FlowStep input")
+        B, C, h, w = z.shape
+        assert C == self.in_channels, (C, self.in_channels)            # FlowActNorms.py:104-109
+        has = hasattr(self, "affine")
+        ft = None
+        if has:
+            ft = rrdbResults if isinstance(rrdbResults, torch.Tensor) else rrdbResults[self.position]   # FlowStep.py:13-15
+            ft = hip._dev_f32(ft, "FlowStep rrdbResults")
+            assert ft.shape == (B, N_RRDB_CH, h, w), (tuple(ft.shape), (B, N_RRDB_CH, h, w))
+        params, layers = self._pack(z.device)
+        lvl = 1 if C == 12 else 2
+        ws = hip.Workspace.get(B, h << lvl, w << lvl, z.device)
+        out = torch.empty_like(z)
+        ld_in = None if logdet is None else _as_logdet(logdet, B, z.device)
+        ld_out = torch.empty(B, dtype=torch.float32, device=z.device)
+        eps = float(self.affine.affine_eps) if has else 0.0
+        with torch.cuda.device(z.device):
+            hip.check(hip.lib().ifl_flow_step(layers, hip._ptr(params), ws.ptr, hip._ptr(z), hip._ptr(out),
+                                              hip._ptr(ft), hip._ptr(ld_in), hip._ptr(ld_out), B, h, w,
+                                              1 if reverse else 0, eps, hip._stream()), "ifl_flow_step")
+        return out, (ld_out if logdet is not None else None)
+
+
+def _as_logdet(logdet, B, device):
+    """The reference accepts a python float (default 0.) or a [B] tensor for logdet."""
+    if isinstance(logdet, torch.Tensor):
+        ld = logdet.to(device=device, dtype=torch.float32).reshape(-1)
+        return (ld.expand(B) if ld.numel() == 1 else ld).contiguous()
+    return torch.full((B,), float(logdet), dtype=torch.float32, device=device)
+
+
+class FlowUpsamplerNet(nn.Module):
+    """FlowUpsamplerNet.py:28-311.  Builds the same layer list and runs encode / decode through the HIP library."""
+
+    def __init__(self, image_shape, hidden_channels, K, L=None, actnorm_scale=1.0, flow_permutation=None,
+                 flow_coupling="affine", LU_decomposed=False, opt=None):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.output_shapes = []
+        self.L = opt_get(opt, ['network_G', 'flow', 'L'])
+        self.K = opt_get(opt, ['network_G', 'flow', 'K'])
+        if isinstance(self.K, int):
+            self.K = [self.K] * (self.L + 1)
+        self.opt = opt
+        H, W, self.C = image_shape
+        assert self.C == 1 or self.C == 3, "image_shape should be HWC, like (64, 64, 3)"      # :198-200
+        if opt['scale'] != 4:
+            raise NotImplementedError("only scale 4 (flow_model.py:40) is in the shipped config")
+        self.levelToName = {0: 'fea_up4', 1: 'fea_up2', 2: 'fea_up1', 3: 'fea_up0', 4: 'fea_up-1'}   # :66-73
+        for unsupported in (['network_G', 'flow', 'norm'], ['network_G', 'flow', 'condAff'],
+                            ['network_G', 'flow', 'condFtAffine'], ['network_G', 'flow', 'levelConditional']):
+            if opt_get(opt, unsupported):
+                raise NotImplementedError(f"option {unsupported} is outside the shipped config")
+        self._kinds = []
+        n_extra = int(opt['network_G']['flow'].get('additionalFlowNoAffine', 0))
+        for level in range(1, self.L + 1):
+            self.C, H, W = self.C * 4, H // 2, W // 2                                      # :183-187
+            self.layers.append(SqueezeLayer(factor=2))
+            self.output_shapes.append([-1, self.C, H, W])
+            self._kinds.append(("squeeze", self.C))
+            for _ in range(n_extra):                                                       # :169-181
+                self.layers.append(FlowStep(in_channels=self.C, hidden_channels=hidden_channels,
+                                            actnorm_scale=actnorm_scale, flow_permutation='invconv',
+                                            flow_coupling='noCoupling', LU_decomposed=LU_decomposed, opt=opt))
+                self.output_shapes.append([-1, self.C, H, W])
+                self._kinds.append(("step0", self.C))
+            for k in range(self.K[level]):                                                 # :122-142
+                self.layers.append(FlowStep(in_channels=self.C, hidden_channels=hidden_channels,
+                                            actnorm_scale=actnorm_scale, flow_permutation='invconv',
+                                            flow_coupling=flow_coupling, LU_decomposed=LU_decomposed, opt=opt,
+                                            idx=k, position='fea_up{}'.format(opt['scale'] / (160 // H))))
+                self.output_shapes.append([-1, self.C, H, W])
+                self._kinds.append(("stepc", self.C))
+            correction = 0 if opt_get(opt, ['network_G', 'flow', 'split', 'correct_splits'], False) else 1
+            if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) and level < self.L - correction:
+                raise NotImplementedError("Split2d layers (Split.py) are not instantiated by the shipped config (L=2)")
+        # dead module the reference registers and never calls (:107-110); kept for the state-dict contract
+        n_aff = (len(opt_get(opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []) + 1) * 64
+        n_f = 2 * 3 * 64 // 2 // 2 if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) else 2 * 3 * 64
+        self.f = nn.Sequential(nn.Conv2d(n_aff, n_f, kernel_size=[3, 3], stride=1, padding=1, bias=True))
+        self.H, self.W = H, W
+        self.scaleH, self.scaleW = 160 / H, 160 / W
+        self._packed = None
+        self.affine_eps = opt_get(opt, ['network_G', 'flow', 'CondAffineSeparatedAndCond', 'eps'], 0.0001)
+
+    # ---- packed parameters, rebuilt when any parameter changes ----
+    def _pack(self, device):
+        key = (_version_key(self.layers), str(device), self.training)
+        if self._packed is None or self._packed[0] != key:
+            prm = _module_params_numpy(self.layers, "layers.")
+            params, layers = pack.pack_flow(prm, self._kinds, training=self.training)
+            self._packed = (key, torch.from_numpy(params).to(device), layers)
+        return self._packed[1], self._packed[2]
+
+    def _level(self, test_input_size, size):
+        ref = 160 if test_input_size is None else test_input_size                        # :230-234, :286-290
+        return int(np.log(ref / size) / np.log(2))
+
+    def _level_features(self, rrdbResults, H, test_input_size, decode):
+        """Apply the reference's per-layer level rule (:228-239 encode, :278-297 decode) and return, per flow
+        level (number of squeezes so far), the conditioning map its FlowSteps use.  Missing keys raise KeyError
+        exactly where the reference would."""
+        if decode:                                                                       # :278-280
+            for lv in range(self.L + 1):
+                rrdbResults[self.levelToName[lv]]
+        feats = {}
+        size_in, flow_level = H, 0
+        for (kind, _), shape in zip(self._kinds, self.output_shapes):
+            size_out = size_in // 2 if kind == "squeeze" else size_in
+            if kind == "squeeze":
+                flow_level += 1
+            if test_input_size is None:
+                size = shape[2]                       # static 160-patch shapes
+            else:
+                size = size_out if decode else size_in    # fl_fea.shape[2] when the layer runs
+            level = self._level(test_input_size, size)
+            if kind == "squeeze":
+                if not decode:
+                    rrdbResults[self.levelToName[level]]      # :239 indexes the dict for every layer
+            else:
+                if decode and level not in range(self.L + 1):
+                    raise KeyError(level)                     # level_conditionals[level], :297
+                ft = rrdbResults[self.levelToName[level]]
+                if flow_level in feats and feats[flow_level] is not ft:
+                    raise NotImplementedError("one conditioning map per flow level expected")
+                feats[flow_level] = ft
+            size_in = size_out
+        return feats
+
+    def forward(self, gt=None, rrdbResults=None, z=None, epses=None, logdet=0., reverse=False, eps_std=None,
+                y_onehot=None, test_input_size=None):
+        if isinstance(epses, list):
+            raise NotImplementedError("epses lists belong to Split2d layers, which the shipped config never creates")
+        if reverse:
+            return self.decode(rrdbResults, z, eps_std, epses=epses, logdet=logdet, y_onehot=y_onehot,
+                               test_input_size=test_input_size)
+        assert gt is not None
+        assert rrdbResults is not None
+        return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot,
+                           test_input_size=test_input_size)
+
+    def _run(self, src, rrdbResults, logdet, test_input_size, decode):
+        src = hip._dev_f32(src, "flow input")
+        B = src.shape[0]
+        if decode:
+            assert src.shape[1] == self.C, (src.shape[1], self.C)
+            H, W = src.shape[2] * 4, src.shape[3] * 4
+            out = torch.empty(B, 3, H, W, dtype=torch.float32, device=src.device)
+        else:
+            assert src.shape[1] == 3, src.shape
+            H, W = src.shape[2], src.shape[3]
+            assert H % 4 == 0 and W % 4 == 0, "{}".format((H, W, 2))                      # flow.py:172
+            out = torch.empty(B, self.C, H // 4, W // 4, dtype=torch.float32, device=src.device)
+        feats = self._level_features(rrdbResults, H, test_input_size, decode)
+        params, layers = self._pack(src.device)
+        ws = hip.Workspace.get(B, H, W, src.device)
+        L = hip.lib()
+        ld_in = _as_logdet(logdet, B, src.device)
+        ld_out = torch.empty(B, dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            for lv, ft in feats.items():
+                ft = hip._dev_f32(ft, f"rrdbResults level {lv}")
+                assert ft.shape == (B, N_RRDB_CH, H >> lv, W >> lv), (tuple(ft.shape), (B, N_RRDB_CH, H >> lv, W >> lv))
+                hip.check(L.ifl_load_cond(ws.ptr, B, H, W, lv, hip._ptr(ft), hip._stream()), "ifl_load_cond")
+            fn = L.ifl_flow_decode if decode else L.ifl_flow_encode
+            hip.check(fn(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
+                         hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps), hip._stream()),
+                      "ifl_flow_decode" if decode else "ifl_flow_encode")
+        return out, ld_out
+
+    def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None, test_input_size=None):
+        return self._run(gt, rrdbResults, logdet, test_input_size, decode=False)
+
+    def decode(self, rrdbResults, z, eps_std=None, epses=None, logdet=0.0, y_onehot=None, test_input_size=None):
+        sr, logdet = self._run(z, rrdbResults, logdet, test_input_size, decode=True)
+        assert sr.shape[1] == 3                                                           # :303
+        return sr, logdet

@@ -1,0 +1,218 @@
+"""ctypes binding of libinterflow_hip.so (C ABI: include/interflow_hip.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers and the
+current HIP stream.  There is no CPU or PyTorch fallback: if the shared library is missing or a
+tensor is not on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinterflow_hip.so")
+
+IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
+
+# field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
+(F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
+ F_W3A, F_W3F, F_B3A, F_B3F) = range(14)
+
+
+class IflLayer(Structure):
+    _fields_ = [("kind", c_int32), ("C", c_int32), ("param_off", c_int64),
+                ("sum_logs", c_float), ("sum_log_s", c_float)]
+
+
+class InterflowHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the library once; fail loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise InterflowHipError(
+            f"{LIB_PATH} not found: build it with `make -C interflow_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.ifl_version.restype = c_int
+    L.ifl_last_error.restype = c_char_p
+    L.ifl_step_param_floats.restype = c_int64
+    L.ifl_step_param_floats.argtypes = [c_int, c_int]
+    L.ifl_step_field_off.restype = c_int64
+    L.ifl_step_field_off.argtypes = [c_int, c_int]
+    L.ifl_ws_bytes.restype = c_int64
+    L.ifl_ws_bytes.argtypes = [c_int, c_int, c_int]
+    L.ifl_ws_init.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p]
+    L.ifl_load_cond.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    flow_args = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                 c_int, c_int, c_int, c_float, c_void_p]
+    L.ifl_flow_encode.argtypes = flow_args
+    L.ifl_flow_decode.argtypes = flow_args
+    L.ifl_flow_step.argtypes = [POINTER(IflLayer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    sq = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_squeeze2d.argtypes = sq
+    L.ifl_unsqueeze2d.argtypes = sq
+    L.ifl_logp_scratch_floats.restype = c_int64
+    L.ifl_logp_scratch_floats.argtypes = [c_int]
+    L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    for name in ("ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
+                 "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_gaussian_logp", "ifl_lerp"):
+        getattr(L, name).restype = c_int
+    _lib = L
+    return L
+
+
+EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
+           "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
+           "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp")
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = lib().ifl_last_error().decode(errors="replace")
+    if rc == IFL_EINVAL:
+        # the reference signals these conditions with `assert` (flow.py:172, FlowActNorms.py:104-109, ...)
+        raise AssertionError(f"{what}: {msg}")
+    if rc == IFL_ENOTSUP:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise InterflowHipError(f"{what}: rc={rc}: {msg}")
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise InterflowHipError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+class Workspace:
+    """Device workspace for one (B, H, W); allocated with torch, initialised by the library."""
+    _cache = {}
+
+    def __init__(self, B, H, W, device):
+        L = lib()
+        nbytes = L.ifl_ws_bytes(B, H + (-H) % 4, W + (-W) % 4)     # FlowStep alone may run on H % 4 == 2 planes
+        if nbytes < 0:
+            check(int(nbytes), "ifl_ws_bytes")
+        self.B, self.H, self.W = B, H, W
+        self.nbytes = nbytes
+        with torch.cuda.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(L.ifl_ws_init(_ptr(self.buf), nbytes, B, H, W, _stream()), "ifl_ws_init")
+
+    @property
+    def ptr(self):
+        return _ptr(self.buf)
+
+    @classmethod
+    def get(cls, B, H, W, device):
+        key = (B, H, W, torch.device(device).index if torch.device(device).index is not None
+               else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        ws = cls._cache.get(key)
+        if ws is None:
+            if len(cls._cache) >= 4:          # a few live shapes at most; drop the oldest
+                cls._cache.pop(next(iter(cls._cache)))
+            ws = cls(B, H, W, device)
+            cls._cache[key] = ws
+        return ws
+
+    @classmethod
+    def clear(cls):
+        cls._cache.clear()
+
+
+# ------------------------------------------------------------------------------------------ operators
+def squeeze2d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
+    """flow.py:163-176"""
+    assert factor >= 1 and isinstance(factor, int)
+    if factor == 1:
+        return x
+    x = _dev_f32(x, "squeeze2d input")
+    B, C, H, W = x.shape
+    assert H % factor == 0 and W % factor == 0, "{}".format((H, W, factor))
+    out = torch.empty(B, C * factor * factor, H // factor, W // factor, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().ifl_squeeze2d(_ptr(x), _ptr(out), B, C, H, W, factor, _stream()), "ifl_squeeze2d")
+    return out
+
+
+def unsqueeze2d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
+    """flow.py:179-193"""
+    assert factor >= 1 and isinstance(factor, int)
+    if factor == 1:
+        return x
+    x = _dev_f32(x, "unsqueeze2d input")
+    B, C, H, W = x.shape
+    assert C % (factor * factor) == 0, "{}".format(C)
+    out = torch.empty(B, C // (factor * factor), H * factor, W * factor, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().ifl_unsqueeze2d(_ptr(x), _ptr(out), B, C, H, W, factor, _stream()), "ifl_unsqueeze2d")
+    return out
+
+
+def gaussian_logp(z: torch.Tensor, mean=None, cov_inv=None, logdet_cov: float = 0.0) -> torch.Tensor:
+    """flow.py:158-161 with the inverse covariance and its log-determinant precomputed by the caller."""
+    z = _dev_f32(z, "gaussian_logp z")
+    B, C, H, W = z.shape
+    out = torch.empty(B, dtype=torch.float32, device=z.device)
+    if B == 0:
+        return out
+    L = lib()
+    scratch = torch.empty(B * L.ifl_logp_scratch_floats(H * W), dtype=torch.float32, device=z.device)
+    if cov_inv is not None:
+        mean = _dev_f32(mean, "mean")
+        cov_inv = _dev_f32(cov_inv, "cov_inv")
+        assert mean.numel() == C and cov_inv.shape == (C, C)
+    with torch.cuda.device(z.device):
+        check(L.ifl_gaussian_logp(_ptr(z), _ptr(mean) if cov_inv is not None else c_void_p(0), _ptr(cov_inv),
+                                  float(logdet_cov), _ptr(scratch), _ptr(out), B, C, H, W, _stream()),
+              "ifl_gaussian_logp")
+    return out
+
+
+def lerp(za: torch.Tensor, zb: torch.Tensor, wa, wb) -> torch.Tensor:
+    """out = wa*za + wb*zb with scalar or per-sample weights (flow_model.py:190,198; train.py:88-92)."""
+    za = _dev_f32(za, "lerp za")
+    zb = _dev_f32(zb, "lerp zb")
+    assert za.shape == zb.shape
+    B = za.shape[0]
+
+    def weights(w):
+        if isinstance(w, torch.Tensor):
+            w = w.to(device=za.device, dtype=torch.float32).reshape(-1)
+            return w.expand(B).contiguous() if w.numel() == 1 else w.contiguous()
+        return torch.full((B,), float(w), dtype=torch.float32, device=za.device)
+    wa_t, wb_t = weights(wa), weights(wb)
+    assert wa_t.numel() == B and wb_t.numel() == B
+    out = torch.empty_like(za)
+    if B == 0:
+        return out
+    with torch.cuda.device(za.device):
+        check(lib().ifl_lerp(_ptr(za), _ptr(zb), _ptr(wa_t), _ptr(wb_t), _ptr(out), B, za[0].numel(), _stream()),
+              "ifl_lerp")
+    return out

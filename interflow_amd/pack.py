@@ -1,0 +1,170 @@
+"""Host-side parameter preparation for the HIP flow kernels.
+
+Takes the reference-format parameters of `FlowUpsamplerNet.layers.*` (numpy float32 arrays keyed as in
+the state dict) and writes the packed block each kernel reads.  Mirrors what the reference recomputes
+on every call in Python (`InvertibleConv1x1.get_weight`, Permutations.py:76-101; `exp(logs)` of the
+ActNorms) plus pure re-orderings of the convolution weights into MFMA fragment order.  The block layout
+is owned by the C library (`ifl_step_field_off`); this file only fills it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hip
+from .synth import HIDDEN, N_RRDB_CH
+
+F32 = np.float32
+
+
+def invconv_matrices(prm, pfx):
+    """W, Winv (float32 [C,C]) and sum(log|det| per pixel) exactly as Permutations.py:76-101 builds them."""
+    if pfx + "weight" in prm:                                   # non-LU branch, Permutations.py:78-86
+        w = prm[pfx + "weight"].astype(F32)
+        winv = np.linalg.inv(w.astype(np.float64)).astype(F32)
+        return w, winv, F32(np.linalg.slogdet(w)[1])
+    p, l, u = prm[pfx + "p"], prm[pfx + "l"], prm[pfx + "u"]
+    log_s, sign_s = prm[pfx + "log_s"], prm[pfx + "sign_s"]
+    C = p.shape[0]
+    l_mask = np.tril(np.ones((C, C), F32), -1)
+    eye = np.eye(C, dtype=F32)
+    lm = (l * l_mask + eye).astype(F32)
+    um = (u * l_mask.T + np.diag(sign_s * np.exp(log_s))).astype(F32)
+    w = (p @ (lm @ um)).astype(F32)
+    li = np.linalg.inv(lm.astype(np.float64)).astype(F32)      # Permutations.py:98-99: inverse in float64, cast
+    ui = np.linalg.inv(um.astype(np.float64)).astype(F32)
+    pinv = np.linalg.inv(p.astype(np.float64)).astype(F32)     # p is a permutation: exact
+    winv = (ui @ (li @ pinv)).astype(F32)
+    return w, winv, F32(np.sum(log_s, dtype=F32))
+
+
+def _acc_channel_order():
+    """Channel held by accumulator element (m, h, r) of the 64 x pixels MFMA block: m*32 + (r&3) + 8*(r>>2) + 4*h,
+    flattened as [m][h][r]."""
+    m, h, r = np.meshgrid(np.arange(2), np.arange(2), np.arange(16), indexing="ij")
+    return (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h).reshape(-1)
+
+
+_ACC = _acc_channel_order()
+
+
+def _pack_conv1(wt, zoff, kz):
+    """wt [64, Cin, 3, 3] -> fragment order.  ft part [cc][tap][kq][mt][h][i][e], then z part [tap][kq][mt][h][i][e]."""
+    wft = wt[:, zoff:zoff + N_RRDB_CH].reshape(2, 32, 10, 4, 2, 4, 9)           # mt i cc kq h e tap
+    out = [np.ascontiguousarray(wft.transpose(2, 6, 3, 0, 4, 1, 5)).reshape(-1)]
+    if kz:
+        wz = np.zeros((HIDDEN, kz, 9), F32)
+        wz[:, :zoff] = wt[:, :zoff].reshape(HIDDEN, zoff, 9)
+        wz = wz.reshape(2, 32, kz // 8, 2, 4, 9)                                 # mt i kq h e tap
+        out.append(np.ascontiguousarray(wz.transpose(5, 2, 0, 3, 1, 4)).reshape(-1))
+    return np.concatenate(out)
+
+
+def _pack_actnorm64(bias, logs):
+    b = bias.reshape(-1)[_ACC]
+    s = np.exp(logs.reshape(-1).astype(F32))[_ACC]
+    return np.concatenate([b, s]).astype(F32)
+
+
+def _pack_conv2(w2):
+    """w2 [64,64,1,1] -> [m2][m][gq][h][i][e] = W[m2*32+i][m*32 + e + 8*gq + 4*h]"""
+    w = w2.reshape(HIDDEN, HIDDEN)
+    m2, m, gq, h, i, e = np.meshgrid(np.arange(2), np.arange(2), np.arange(4), np.arange(2), np.arange(32),
+                                     np.arange(4), indexing="ij")
+    return w[m2 * 32 + i, m * 32 + e + 8 * gq + 4 * h].reshape(-1).astype(F32)
+
+
+def _row_map(C, net):
+    """Original Conv2dZeros output row for (tile, q, r), or -1.  net 0 = fAffine (rows 2*c2 + s for z2 channel
+    c2), net 1 = fFeatures (rows 2*c + s).  slot sigma = 8*tile + 2*q + (r&1), s = r>>1 (0 shift, 1 scale)."""
+    ch = C // 2
+    ntile = -(-ch // 8) if net == 0 else -(-C // 8)
+    rows = np.full((ntile, 4, 4), -1, np.int64)
+    for t in range(ntile):
+        for q in range(4):
+            for r in range(4):
+                sigma = 8 * t + 2 * q + (r & 1)
+                s = r >> 1
+                if net == 0:
+                    if sigma < ch:
+                        rows[t, q, r] = 2 * sigma + s
+                elif sigma < C:
+                    rows[t, q, r] = 2 * ((sigma + ch) % C) + s
+    return rows
+
+
+def _pack_conv3(w3, bias, logs, C, net):
+    rows = _row_map(C, net)                                   # [tile][q][r]
+    ntile = rows.shape[0]
+    flat = rows.reshape(ntile, 16)                            # row index inside the tile = 4*q + r
+    wsrc = np.concatenate([w3.reshape(w3.shape[0], HIDDEN, 9), np.zeros((1, HIDDEN, 9), F32)])
+    wperm = wsrc[flat]                                        # [tile][16][64][9]; -1 picks the zero row
+    # -> [tile][tap][sidx][kq4][i][e] with ci = 16*sidx + 4*kq4 + e
+    wperm = wperm.reshape(ntile, 16, 4, 4, 4, 9)              # tile i sidx kq4 e tap
+    wp = np.ascontiguousarray(wperm.transpose(0, 5, 2, 3, 1, 4)).reshape(-1).astype(F32)
+    bsrc = np.concatenate([bias.reshape(-1), np.zeros(1, F32)])
+    esrc = np.concatenate([np.exp((logs.reshape(-1) * F32(3.0)).astype(F32)), np.zeros(1, F32)])
+    bp = np.stack([bsrc[rows], esrc[rows]], axis=1)           # [tile][2][q][r]
+    return wp, bp.reshape(-1).astype(F32)
+
+
+def pack_step(prm, pfx, C, has_coupling, out, training=False):
+    """Fill `out` (float32 view of the step's block).  Returns (sum_logs, sum_log_s)."""
+    L = hip.lib()
+
+    def put(field, arr):
+        o = L.ifl_step_field_off(C, field)
+        out[o:o + arr.size] = arr.reshape(-1)
+
+    bias = prm[pfx + "actnorm.bias"].reshape(-1).astype(F32)
+    logs = prm[pfx + "actnorm.logs"].reshape(-1).astype(F32)
+    if training and not np.any(bias != 0):
+        raise NotImplementedError(
+            "data-dependent ActNorm initialisation (FlowActNorms.py:29-43) is not implemented in the HIP path; "
+            "load initialised parameters or call .eval()")
+    w, winv, sum_log_s = invconv_matrices(prm, pfx + "invconv.")
+    put(hip.F_ANIC_FWD, np.concatenate([bias, np.exp(logs), w.reshape(-1)]))
+    put(hip.F_ANIC_INV, np.concatenate([bias, np.exp(-logs), winv.reshape(-1)]))
+    if has_coupling:
+        ch = C // 2
+        kz = -(-ch // 8) * 8
+        for net, name, fw1, fan1, fw2, fan2, fw3, fb3 in (
+                (0, "affine.fAffine.", hip.F_W1A, hip.F_AN1A, hip.F_W2A, hip.F_AN2A, hip.F_W3A, hip.F_B3A),
+                (1, "affine.fFeatures.", hip.F_W1F, hip.F_AN1F, hip.F_W2F, hip.F_AN2F, hip.F_W3F, hip.F_B3F)):
+            q = pfx + name
+            if training and not np.any(prm[q + "0.actnorm.bias"] != 0):
+                raise NotImplementedError("data-dependent ActNorm initialisation is not implemented in the HIP path")
+            put(fw1, _pack_conv1(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0, kz if net == 0 else 0))
+            put(fan1, _pack_actnorm64(prm[q + "0.actnorm.bias"], prm[q + "0.actnorm.logs"]))
+            put(fw2, _pack_conv2(prm[q + "2.weight"].astype(F32)))
+            put(fan2, _pack_actnorm64(prm[q + "2.actnorm.bias"], prm[q + "2.actnorm.logs"]))
+            wp, bp = _pack_conv3(prm[q + "4.weight"].astype(F32), prm[q + "4.bias"].astype(F32),
+                                 prm[q + "4.logs"].astype(F32), C, net)
+            put(fw3, wp)
+            put(fb3, bp)
+    return float(np.sum(logs, dtype=F32)), float(sum_log_s)
+
+
+def pack_flow(prm, kinds, pfx="", training=False):
+    """kinds: list of (kind, C) per layer, kind in {"squeeze","step0","stepc"} (synth.layer_plan order).
+    Returns (params float32 ndarray, ctypes array of IflLayer)."""
+    L = hip.lib()
+    offs, total = [], 0
+    for kind, C in kinds:
+        offs.append(total)
+        if kind != "squeeze":
+            total += L.ifl_step_param_floats(C, 1 if kind == "stepc" else 0)
+    params = np.zeros(max(total, 1), F32)
+    layers = (hip.IflLayer * len(kinds))()
+    for i, (kind, C) in enumerate(kinds):
+        layers[i].C = C
+        layers[i].param_off = offs[i]
+        if kind == "squeeze":
+            layers[i].kind = 0
+            continue
+        has = kind == "stepc"
+        layers[i].kind = 2 if has else 1
+        n = L.ifl_step_param_floats(C, 1 if has else 0)
+        sl, ss = pack_step(prm, f"{pfx}layers.{i}.", C, has, params[offs[i]:offs[i] + n], training)
+        layers[i].sum_logs = sl
+        layers[i].sum_log_s = ss
+    return params, layers

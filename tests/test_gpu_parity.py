@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-generated golden fixtures and the
+CPU oracle.  Tolerance for floating point: rel 1e-4 of the tensor's max magnitude (BASELINE.json north_star);
+index permutations are compared bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from interflow_amd import hip, synth
+from interflow_amd.flow_model import Gaussian, InterpFlow
+from oracle import interflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+SCALES = [2, 4]
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_close(got, want, tol=RTOL, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), what
+    scale = max(float(np.abs(want).max()), 1e-30)
+    err = float(np.abs(got - want).max()) / scale
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e}"
+    return err
+
+
+@pytest.fixture(scope="module")
+def sd_np():
+    return synth.synth_interpflow_state(SCALES, seed=0)
+
+
+@pytest.fixture(scope="module")
+def model(sd_np):
+    m = InterpFlow(SCALES)
+    m.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+    return m.eval().to(dev())
+
+
+@pytest.fixture(scope="module")
+def sd(sd_np):
+    return O.to_torch(sd_np)
+
+
+def load(golden_dir, name, sd_np):
+    g = np.load(os.path.join(golden_dir, name))
+    assert str(g["digest"]) == synth.state_digest(sd_np), "synthesised weights differ from the fixture's"
+    return g
+
+
+# ----------------------------------------------------------------------------- K1 permutations (bit exact)
+@pytest.mark.parametrize("shape,f", [((2, 3, 6, 10), 2), ((1, 12, 80, 80), 2), ((3, 3, 160, 160), 2),
+                                     ((2, 3, 8, 16), 4), ((1, 1, 2, 2), 2), ((0, 3, 4, 4), 2), ((5, 7, 6, 9), 3)])
+def test_squeeze_bit_exact(shape, f):
+    x = torch.randn(*shape)
+    want = O.squeeze2d(x, f)
+    got = hip.squeeze2d(x.to(dev()), f)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(hip.unsqueeze2d(got, f).cpu(), x)
+
+
+def test_squeeze_golden_and_errors(golden_dir, sd_np):
+    g = load(golden_dir, "ops_seed0.npz", sd_np)
+    assert np.array_equal(hip.squeeze2d(t(g["sq_in"]).to(dev())).cpu().numpy(), g["sq_out"])
+    assert np.array_equal(hip.unsqueeze2d(t(g["unsq_in"]).to(dev())).cpu().numpy(), g["unsq_out"])
+    assert np.array_equal(hip.squeeze2d(t(g["sq_in"][:, :, :4, :8]).to(dev()), 4).cpu().numpy(), g["sq4_out"])
+    with pytest.raises(AssertionError):
+        hip.squeeze2d(torch.zeros(1, 3, 5, 4, device=dev()))          # flow.py:172
+    with pytest.raises(AssertionError):
+        hip.unsqueeze2d(torch.zeros(1, 6, 4, 4, device=dev()))        # flow.py:189
+
+
+# ----------------------------------------------------------------------------- one FlowStep (K2, K3, K4)
+@pytest.mark.parametrize("tag", ["c12", "c48", "c12n", "c48n"])
+def test_flow_step_golden(golden_dir, sd_np, model, tag):
+    g = load(golden_dir, "ops_seed0.npz", sd_np)
+    step = model.flow_upsampler.layers[int(g[f"{tag}_layer"])]
+    z, ld, ft = (t(g[f"{tag}_{k}"]).to(dev()) for k in ("z", "ld", "ft"))
+    out, ldo = step(z, ld, reverse=False, rrdbResults=ft)
+    rel_close(out, g[f"{tag}_step_enc"], what=f"{tag} enc z")
+    rel_close(ldo, g[f"{tag}_step_enc_ld"], what=f"{tag} enc logdet")
+    out, ldo = step(z, ld, reverse=True, rrdbResults=ft)
+    rel_close(out, g[f"{tag}_step_dec"], what=f"{tag} dec z")
+    rel_close(ldo, g[f"{tag}_step_dec_ld"], what=f"{tag} dec logdet")
+
+
+@pytest.mark.parametrize("li,hw", [(3, (1, 1)), (3, (2, 34)), (22, (1, 3)), (22, (11, 13)), (5, (16, 40)), (30, (9, 40))])
+def test_flow_step_oracle_ragged(sd, model, li, hw):
+    """Sizes that exercise partial tiles, single pixels and band remainders; inverse undoes forward."""
+    step = model.flow_upsampler.layers[li]
+    C = step.in_channels
+    g = torch.Generator().manual_seed(li * 100 + hw[0])
+    z = torch.randn(2, C, *hw, generator=g)
+    ft = torch.randn(2, 320, *hw, generator=g)
+    ld = torch.randn(2, generator=g)
+    p = f"flow_upsampler.layers.{li}."
+    zw, lw = O.flow_step(z, ld, False, ft, sd, p)
+    out, ldo = step(z.to(dev()), ld.to(dev()), reverse=False, rrdbResults=ft.to(dev()))
+    rel_close(out, zw, what="enc z"); rel_close(ldo - ld.to(dev()), lw - ld, 2e-4, what="enc dlogdet")
+    back, ldb = step(out, ldo, reverse=True, rrdbResults=ft.to(dev()))
+    rel_close(back, z, what="round trip"); rel_close(ldb, ld, 1e-3, what="round trip logdet")
+    zw, lw = O.flow_step(z, ld, True, ft, sd, p)
+    out, ldo = step(z.to(dev()), ld.to(dev()), reverse=True, rrdbResults=ft.to(dev()))
+    rel_close(out, zw, what="dec z"); rel_close(ldo - ld.to(dev()), lw - ld, 2e-4, what="dec dlogdet")
+
+
+# ----------------------------------------------------------------------------- whole stack
+def test_stack32_golden(golden_dir, sd_np, model):
+    g = load(golden_dir, "stack32_seed0.npz", sd_np)
+    B, H = 2, 32
+    x = t(synth.synth_images(11, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(12, B, H, H).items()}
+    fu = model.flow_upsampler
+    for tis, tag in ((None, "tisNone"), (H, "tis")):
+        z, ld = fu(gt=x, rrdbResults=feats, logdet=torch.zeros(B, device=dev()), reverse=False, test_input_size=tis)
+        rel_close(z, g[f"{tag}_z"], what="z"); rel_close(ld, g[f"{tag}_ld"], what="logdet")
+        xr, ldr = fu(z=t(g[f"{tag}_z"]).to(dev()), rrdbResults=feats, logdet=torch.zeros(B, device=dev()),
+                     reverse=True, test_input_size=tis)
+        rel_close(xr, g[f"{tag}_xr"], what="x"); rel_close(ldr, g[f"{tag}_ldr"], what="logdet rev")
+    x = t(synth.synth_images(13, 1, 20, 36)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(14, 1, 20, 36).items()}
+    z, ld = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+    rel_close(z, g["odd_z"], what="odd z"); rel_close(ld, g["odd_ld"], what="odd logdet")
+    xr, ldr = fu(z=t(g["odd_z"]).to(dev()), rrdbResults=feats, logdet=0., reverse=True)
+    rel_close(xr, g["odd_xr"], what="odd x"); rel_close(ldr, g["odd_ldr"], what="odd logdet rev")
+    with pytest.raises(KeyError):                                       # FlowUpsamplerNet.py:279-280 needs fea_up4
+        fu(z=z, rrdbResults={k: v for k, v in feats.items() if k != "fea_up4"}, reverse=True)
+    with pytest.raises(AssertionError):                                 # flow.py:172
+        fu(gt=torch.zeros(1, 3, 18, 20, device=dev()), rrdbResults=feats, reverse=False)
+
+
+def test_full160_golden(golden_dir, sd_np, model):
+    """BASELINE.json configs[0]/[1] shape (160x160 patches), reference outputs for B=2."""
+    g = load(golden_dir, "full160_seed0.npz", sd_np)
+    B, H = 2, 160
+    x = t(synth.synth_images(1, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(2, B, H, H).items()}
+    z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    e1 = rel_close(z, g["z"], what="z"); e2 = rel_close(ld, g["ld"], what="logdet")
+    xr, ldr = model(t(g["z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False)
+    e3 = rel_close(xr, g["xr"], what="x"); e4 = rel_close(ldr, g["ldr"], what="logdet rev")
+    print(f"full160 rel errs: z {e1:.2e} logdet {e2:.2e} x {e3:.2e} logdet_rev {e4:.2e}")
+
+
+def test_batch32_properties(golden_dir, sd_np, model):
+    """BASELINE.json configs[1]: batch 32.  Size-independent properties: samples are independent (the first two
+    reproduce the B=2 golden), decode inverts encode, and the log-dets cancel."""
+    g = load(golden_dir, "full160_seed0.npz", sd_np)
+    B, H = 32, 160
+    x2 = synth.synth_images(1, 2, H, H)
+    f2 = synth.synth_features(2, 2, H, H)
+    x = t(np.concatenate([x2, synth.synth_images(7, B - 2, H, H)])).to(dev())
+    fb = synth.synth_features(8, B - 2, H, H)
+    feats = {k: t(np.concatenate([f2[k], fb[k]])).to(dev()) for k in f2}
+    z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    rel_close(z[:2], g["z"], what="z[:2]"); rel_close(ld[:2], g["ld"], what="logdet[:2]")
+    xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
+    rel_close(xr, x, what="decode(encode(x))"); rel_close(-ldr, ld, what="logdet cancels")
+    # permuting the batch permutes the outputs (no cross-sample coupling)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(dev())
+    zp, ldp = model(x[perm], None, lr_enc={k: v[perm] for k, v in feats.items()}, add_gt_noise=False, calc_loss=False)
+    assert torch.equal(zp, z[perm]) and torch.equal(ldp, ld[perm])
+
+
+# ----------------------------------------------------------------------------- model API incl. encoder, prior, lerp
+def test_api64_golden(golden_dir, sd_np, model):
+    g = load(golden_dir, "api64_seed0.npz", sd_np)
+    B, H = 2, 64
+    gt, lr2, lr4 = (t(synth.synth_images(s, B, H, H)).to(dev()) for s in (21, 22, 23))
+    with torch.no_grad():
+        lr_enc = model.arch.rrdbPreprocessing(gt)
+        rel_close(lr_enc["fea_up1"], g["enc_fea_up1"], what="fea_up1")
+        z, nll, ld, ll_ib = model(lr2, gt, torch.tensor([2, 4]), lr_enc=lr_enc, add_gt_noise=False)
+        rel_close(z, g["z"], 2e-4, what="z"); rel_close(ld, g["ld"], what="logdet")
+        rel_close(nll, g["nll"], what="nll"); rel_close(ll_ib, g["ll_ib"], 1e-3, what="ll_ib")
+        z2, ld2 = model(lr4, gt, add_gt_noise=False, calc_loss=False)          # recomputes lr_enc internally
+        rel_close(z2, g["z2"], 2e-4, what="z2"); rel_close(ld2, g["ld2"], what="logdet2")
+        _, ldr = model(t(g["z"]).to(dev()), gt, reverse=True, add_gt_noise=True, test_input_size=H, lr_enc=lr_enc)
+        rel_close(ldr, g["xr_noise_ld"], what="logdet rev with noise term")
+        out = model.weighted_interpolate_image(lr2, lr4, 0.35, cond_gt=gt)
+        rel_close(out, g["wi_035"], 2e-4, what="weighted_interpolate_image")
+        out = model.interpolate_image(lr2, 2, lr4, 4, 2.6, cond_gt=gt)
+        rel_close(out, g["interp_26"], 2e-4, what="interpolate_image")
+        # noise path: logdet offset is -ln(256)*H*W (flow_model.py:110), z stays close to the noiseless z
+        torch.manual_seed(0)
+        zn, ldn = model(lr2, gt, lr_enc=lr_enc, add_gt_noise=True, calc_loss=False)
+        assert abs(float((ldn - ld).mean()) + np.log(256) * H * H) < 0.02 * H * H
+        with pytest.raises(AssertionError):
+            model(lr2, gt, torch.tensor([2, 4, 4]), lr_enc=lr_enc, add_gt_noise=False)   # flow_model.py:130
+
+
+def test_gaussian_prior_and_loss(golden_dir, sd_np, sd, model):
+    g = load(golden_dir, "ops_seed0.npz", sd_np)
+    z = t(g["g_z"]).to(dev())
+    rel_close(Gaussian.logp(None, None, z), g["g_std"], what="standard normal")
+    cov = model.cov_shift_1 @ model.cov_shift_1.T
+    mean = model.mean_shift_1 * torch.ones(48, device=dev())
+    rel_close(Gaussian.logp(mean, cov, z), g["g_shift"], what="shifted")
+    _, nll, _, ll_ib = model.calculate_loss(z, t(g["loss_ld"]).to(dev()), 20 * 24, t(g["loss_label"]).to(dev()))
+    rel_close(nll, g["loss_nll"], what="nll"); rel_close(ll_ib, g["loss_ll_ib"], 1e-3, what="ll_ib")
+    rel_close(model.get_pdf(z, [2, 4]), g["pdf"], what="get_pdf")
+    # larger, odd-sized case against the oracle, other channel counts
+    for C, hw in ((48, (40, 40)), (12, (7, 9)), (5, (3, 300))):
+        zz = torch.randn(3, C, *hw, generator=torch.Generator().manual_seed(C))
+        rel_close(hip.gaussian_logp(zz.to(dev())), O.gaussian_logp(None, None, zz), what=f"std C={C}")
+        a = torch.randn(C, C, generator=torch.Generator().manual_seed(1)) * 0.1 + torch.eye(C)
+        cov, mu = a @ a.T, torch.randn(C, generator=torch.Generator().manual_seed(2))
+        got = hip.gaussian_logp(zz.to(dev()), mu.to(dev()), torch.inverse(cov).to(dev()), float(torch.slogdet(cov)[1]))
+        rel_close(got, O.gaussian_logp(mu, cov, zz), what=f"full C={C}")
+
+
+def test_lerp():
+    gen = torch.Generator().manual_seed(3)
+    z1, z2 = torch.randn(4, 48, 40, 40, generator=gen), torch.randn(4, 48, 40, 40, generator=gen)
+    a = 0.35
+    want = (1 - a) * z1 + a * z2
+    got = hip.lerp(z1.to(dev()), z2.to(dev()), 1 - a, a)
+    rel_close(got, want, 1e-6, what="scalar weights")
+    w = torch.rand(4, generator=gen)
+    want = (1 - w).reshape(-1, 1, 1, 1) * z1 + w.reshape(-1, 1, 1, 1) * z2      # train.py:88-92
+    assert torch.equal(hip.lerp(z1.to(dev()), z2.to(dev()), 1 - w, w).cpu(), want)
+    z1, z2 = torch.randn(2, 3, 5, 7, generator=gen), torch.randn(2, 3, 5, 7, generator=gen)   # n % 4 != 0
+    assert torch.equal(hip.lerp(z1.to(dev()), z2.to(dev()), w[:2], 1 - w[:2]).cpu(),
+                       w[:2].reshape(-1, 1, 1, 1) * z1 + (1 - w[:2]).reshape(-1, 1, 1, 1) * z2)

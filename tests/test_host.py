@@ -1,0 +1,92 @@
+"""CPU-only checks of the host side: state-dict contract, C-ABI exports, parameter packing layout, error paths."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from interflow_amd import hip, pack, synth
+from interflow_amd.flow_model import InterpFlow
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model():
+    return InterpFlow([2, 4])
+
+
+def test_state_dict_contract(golden_dir, model):
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(keys)
+    for k, shp in keys.items():
+        assert list(sd[k].shape) == shp, k
+    sd_np = synth.synth_interpflow_state([2, 4], seed=0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    # aliases share storage, as in the reference (flow_model.py:53-55)
+    assert model.flow_upsampler is model.arch.flowUpsamplerNet and model.rrdb is model.arch.RRDB
+    assert model.classes == [2, 4] and model.C == 48
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "interflow_hip.h")).read()
+    declared = set(re.findall(r"\b(ifl_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    L = hip.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.ifl_version() == 1
+
+
+def test_param_block_layout():
+    L = hip.lib()
+    for C in (12, 48):
+        offs = [L.ifl_step_field_off(C, f) for f in range(14)]
+        assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+        assert L.ifl_step_param_floats(C, 1) > offs[-1]
+        assert L.ifl_step_param_floats(C, 0) == offs[2]          # only the two ActNorm+1x1 blocks
+    assert L.ifl_ws_bytes(2, 30, 32) == hip.IFL_EINVAL           # not a multiple of 4 (flow.py:172)
+    assert L.ifl_ws_bytes(2, 32, 32) > 0
+
+
+def test_pack_flow_shapes_and_invconv():
+    sd = synth.synth_flow_state(seed=3, K=1, extra=1)
+    kinds = synth.layer_plan(K=1, extra=1)
+    params, layers = pack.pack_flow(sd, kinds)
+    assert len(layers) == len(kinds) == 6
+    assert [l.kind for l in layers] == [0, 1, 2, 0, 1, 2]
+    assert np.isfinite(params).all()
+    w, winv, sls = pack.invconv_matrices(sd, "layers.1.invconv.")
+    np.testing.assert_allclose(w @ winv, np.eye(12), atol=2e-6)
+    assert abs(sls - np.log(abs(np.linalg.det(w.astype(np.float64))))) < 1e-5
+    # conv1 packing is a pure permutation (plus zero padding of the z1 channels)
+    wt = sd["layers.2.affine.fAffine.0.weight"]
+    p = pack._pack_conv1(wt, 6, 8)
+    assert p.size == 64 * 9 * 328 and np.isclose(np.abs(p).sum(), np.abs(wt).sum(), rtol=1e-6)
+    np.testing.assert_array_equal(np.sort(p[p != 0]), np.sort(wt.reshape(-1)[wt.reshape(-1) != 0]))
+    rows = pack._row_map(12, 1)
+    assert sorted(rows[rows >= 0].tolist()) == list(range(24))    # every fFeatures row placed exactly once
+    rows = pack._row_map(48, 0)
+    assert sorted(rows[rows >= 0].tolist()) == list(range(48))
+
+
+def test_training_mode_with_uninitialised_actnorm_is_rejected():
+    sd = synth.synth_flow_state(seed=3, K=1, extra=1)
+    sd["layers.1.actnorm.bias"] = np.zeros_like(sd["layers.1.actnorm.bias"])
+    with pytest.raises(NotImplementedError):
+        pack.pack_flow(sd, synth.layer_plan(K=1, extra=1), training=True)
+
+
+def test_cpu_tensors_are_rejected(model):
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(hip.InterflowHipError):
+        hip.squeeze2d(x)
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(0, 1, 8, 8).items()}
+    with pytest.raises(hip.InterflowHipError):
+        model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    with pytest.raises(NotImplementedError):
+        model(None, x, reverse=True)                              # flow_model.py:85-86
