@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- flow fwd+inv patches/sec (160x160, fp32) on N MI355X  (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch: `InterpFlow.forward` encode (x -> z, logdet) followed by the
+decode (z -> x) of BASELINE.json configs[1]: batch 32 of synthetic 160x160 RGB patches per GPU, fp32,
+conditioning features (`lr_enc`) precomputed, resident in HBM and shared by the two passes, `add_gt_noise=False`
+(SURVEY.md section 8(d)).  Nothing is cached between steps: every step converts the conditioning maps to the
+kernels' layout again and runs all 38 layers in both directions.
+
+Multi-GPU (`torchrun --nproc-per-node N bench.py --gpus N`): one process per GPU, each with its own batch of 32
+(weak scaling, no data-path collective); the barrier and the max-over-ranks time use RCCL.
+
+Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel (the coupling networks'
+first conv, timed live with HIP events on the launch stream) and, at N=1, the CPU oracle timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from interflow_amd import hip, synth  # noqa: E402
+from interflow_amd.flow_model import InterpFlow  # noqa: E402
+
+PATCH = 160
+BATCH = 32
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+SCALES = [2, 4]
+
+
+def conv1_macs_per_pixel(C):
+    """Algorithmic MACs per pixel of one conditional step's first two conv layers, both networks
+    (SURVEY.md section 8(a) row a11): 3x3 (C/2+320 -> 64), 3x3 (320 -> 64), two 1x1 (64 -> 64)."""
+    return 64 * 9 * (C // 2 + 320) + 64 * 9 * 320 + 2 * 64 * 64
+
+
+def cpu_baseline(sd_np, seconds_budget=20.0):
+    """The CPU oracle (port of the reference, pinned to it by tests/golden) on BASELINE.json configs[0]:
+    4 patches, fp32, encode + decode with precomputed features, all host threads torch chooses."""
+    from oracle import interflow_oracle as O
+    sd = O.to_torch(sd_np)
+    B = 4
+    x = torch.from_numpy(synth.synth_images(1, B, PATCH, PATCH))
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(2, B, PATCH, PATCH).items()}
+    threads = torch.get_num_threads()
+
+    def one():
+        z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B))
+        O.flow_decode(z, feats, sd, "flow_upsampler.", torch.zeros(B))
+    with torch.no_grad():
+        one()                                   # warm-up
+        times = []
+        t_end = time.perf_counter() + seconds_budget
+        while len(times) < 10 and (time.perf_counter() < t_end or len(times) < 2):
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} timed encode+decode passes of 4 patches 160x160 (BASELINE configs[0]) after 1 warm-up; median {med:.3f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="patches per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.eval().to(dev)
+
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.rand(B, 3, PATCH, PATCH, device=dev, generator=gen)
+    a = float(np.sqrt(3.0))
+    feats = {k: (torch.rand(B, 320, PATCH // d, PATCH // d, device=dev, generator=gen) * 2 - 1) * a
+             for k, d in (("fea_up4", 1), ("fea_up2", 2), ("fea_up1", 4))}
+
+    def step():
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        return z, ld, xr, ldr
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        hip.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    z, ld, xr, ldr = out
+    err = float((xr - x).abs().max())
+    assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
+
+    # kernel timing (HIP events recorded on the launch stream during the timed region)
+    prof = {}
+    for name, kid in (("conv1_enc_l1", hip.K_CONV1_ENC_L1), ("conv1_enc_l2", hip.K_CONV1_ENC_L2),
+                      ("conv1_dec_l1", hip.K_CONV1_DEC_L1), ("conv1_dec_l2", hip.K_CONV1_DEC_L2),
+                      ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC)):
+        ms, n = hip.prof_read(kid)
+        prof[name] = (ms, n)
+    hip.prof_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        patches = world * B * args.steps
+        value = patches / elapsed
+        # dominant kernel: conv1 (both networks) of the encode pass at level 1 (C=12, 80x80 planes)
+        ms1, n1 = prof["conv1_enc_l1"]
+        px1 = (PATCH // 2) ** 2
+        flops_launch = 2.0 * conv1_macs_per_pixel(12) * px1 * B
+        avg_ms = ms1 / max(n1, 1)
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if n1 else None
+        total_conv1_flops = 0.0
+        for lvl, C in ((1, 12), (2, 48)):
+            px = (PATCH >> lvl) ** 2
+            total_conv1_flops += 2 * 16 * 2.0 * conv1_macs_per_pixel(C) * px * B     # 16 steps, encode + decode
+        conv1_ms = sum(prof[k][0] for k in ("conv1_enc_l1", "conv1_enc_l2", "conv1_dec_l1", "conv1_dec_l2"))
+        res = {
+            "metric": "flow fwd+inv patches/sec (160x160, fp32)",
+            "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"InterFlow flow encode+decode, batch {B} of 160x160 RGB patches per GPU, fp32, "
+                                   "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
+                                   "add_gt_noise=False (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)"},
+            "roofline": {"bound": "mfma", "kernel": "conv1_kernel<64,2> (coupling-network 3x3+1x1 convs, level 1, encode)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": n1, "flops_per_launch": flops_launch},
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "conv1_all_tflops": total_conv1_flops * args.steps / (conv1_ms * 1e-3) / 1e12 if conv1_ms else None,
+            "path_tflops": 213.1e9 * B * args.steps / elapsed / 1e12,
+            "roundtrip_max_abs_err": err,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd_np)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,23 @@ int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, f
 int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,
              int B, int64_t n_per_sample, void* stream);
 
+/* ---- opt-in kernel timing (no counterpart in the reference; measurement aid for bench.py) ----
+ * While enabled, the flow drivers bracket each launch of the kernels below with a pair of HIP events
+ * recorded on the caller's stream (events are created on demand: the "no allocation" rule above holds
+ * only while timing is off).  ifl_prof_read synchronises on those events and returns the summed
+ * duration and the number of launches of one kernel id; ifl_prof_enable(0) frees the events.       */
+enum {
+    IFL_K_CONV1_ENC_L1 = 0,   /* conv1, both networks, level 1 (C = 12) */
+    IFL_K_CONV1_ENC_L2 = 1,   /* conv1, both networks, level 2 (C = 48) */
+    IFL_K_CONV1_DEC_L1 = 2,   /* conv1, one network per launch, level 1 */
+    IFL_K_CONV1_DEC_L2 = 3,
+    IFL_K_CONV3_ENC = 4,
+    IFL_K_CONV3_DEC = 5,
+    IFL_K_ANIC = 6
+};
+int ifl_prof_enable(int on);
+int ifl_prof_read(int kernel_id, double* total_ms, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

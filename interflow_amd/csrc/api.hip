@@ -17,6 +17,51 @@ void ifl_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* ifl_last_error(void) { return g_err; }
+
+// ---- opt-in per-kernel timing with HIP events on the caller's stream (used by bench.py for the roofline figure) ----
+#include <vector>
+namespace {
+struct ProfRec { int id; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+struct ProfScope {
+    hipStream_t st; hipEvent_t b = nullptr;
+    ProfScope(int id, hipStream_t s) : st(s) {
+        if (!g_prof_on) return;
+        ProfRec r{id, nullptr, nullptr};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, st);
+        b = r.b;
+        g_prof.push_back(r);
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
+};
+}  // namespace
+
+extern "C" int ifl_prof_enable(int on)
+{
+    if (!on) {
+        for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        g_prof.clear();
+    }
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int ifl_prof_read(int kernel_id, double* total_ms, int64_t* count)
+{
+    double tot = 0; int64_t n = 0;
+    for (auto& r : g_prof) {
+        if (r.id != kernel_id) continue;
+        float ms = 0;
+        IFL_HIP(hipEventSynchronize(r.b));
+        IFL_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms; ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return 0;
+}
 extern "C" int ifl_version(void) { return IFL_VERSION; }
 
 extern "C" int64_t ifl_step_param_floats(int C, int has_coupling) { return ifl_step_off(C, has_coupling).total; }
@@ -97,7 +142,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
 
 static int check_shape(int B, int H, int W, int div = 4)
 {
-    IFL_CHECK_ARG(B >= 1 && H >= 4 && W >= 4, IFL_EINVAL, "bad shape B=%d H=%d W=%d", B, H, W);
+    IFL_CHECK_ARG(B >= 1 && H >= div && W >= div, IFL_EINVAL, "bad shape B=%d H=%d W=%d", B, H, W);
     IFL_CHECK_ARG(H % div == 0 && W % div == 0, IFL_EINVAL, "H=%d, W=%d must be multiples of %d (flow.py:172)", H, W, div);
     IFL_CHECK_ARG((int64_t)(H / 2 + 2) * (W / 2 + 2) * IFL_FT < (int64_t)1 << 31, IFL_ENOTSUP,
                   "image plane too large for 32-bit tile offsets: tile the image");
@@ -144,13 +189,18 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
-    int rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, st);
+    int rc;
+    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, st); }
     if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
     if (L.kind == 2) {
-        if ((rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 2, st))) return rc;
-        if ((rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st))) return rc;
+        { ProfScope ps(lv.C == 12 ? IFL_K_CONV1_ENC_L1 : IFL_K_CONV1_ENC_L2, st);
+          rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 2, st); }
+        if (rc) return rc;
+        { ProfScope ps(IFL_K_CONV3_ENC, st);
+          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
+        if (rc) return rc;
         slots += lv.geom.ntiles;
     }
     return 0;
@@ -163,14 +213,22 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
     const float* prm = params + L.param_off;
     int rc;
     if (L.kind == 2) {
-        if ((rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 1, st))) return rc;
-        if ((rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st))) return rc;
+        const int kid = lv.C == 12 ? IFL_K_CONV1_DEC_L1 : IFL_K_CONV1_DEC_L2;
+        { ProfScope ps(kid, st); rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 1, st); }
+        if (rc) return rc;
+        { ProfScope ps(IFL_K_CONV3_DEC, st);
+          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
+        if (rc) return rc;
         slots += lv.geom.ntiles;
-        if ((rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 0, st))) return rc;
-        if ((rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st))) return rc;
+        { ProfScope ps(kid, st); rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 0, st); }
+        if (rc) return rc;
+        { ProfScope ps(IFL_K_CONV3_DEC, st);
+          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
+        if (rc) return rc;
         slots += lv.geom.ntiles;
     }
-    if ((rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, st))) return rc;
+    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, st); }
+    if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant -= (double)L.sum_logs * px + (double)L.sum_log_s * px;
     return 0;

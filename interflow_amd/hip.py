@@ -68,6 +68,10 @@ def lib():
     L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    L.ifl_prof_enable.argtypes = [c_int]
+    L.ifl_prof_enable.restype = c_int
+    L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
+    L.ifl_prof_read.restype = c_int
     for name in ("ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
                  "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_gaussian_logp", "ifl_lerp"):
         getattr(L, name).restype = c_int
@@ -77,7 +81,21 @@ def lib():
 
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
-           "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp")
+           "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
+           "ifl_prof_enable", "ifl_prof_read")
+
+K_CONV1_ENC_L1, K_CONV1_ENC_L2, K_CONV1_DEC_L1, K_CONV1_DEC_L2, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
+
+
+def prof_enable(on: bool):
+    check(lib().ifl_prof_enable(1 if on else 0), "ifl_prof_enable")
+
+
+def prof_read(kernel_id: int):
+    """(total milliseconds, launches) of one kernel id since timing was enabled."""
+    ms, n = ctypes.c_double(0), c_int64(0)
+    check(lib().ifl_prof_read(kernel_id, ctypes.byref(ms), ctypes.byref(n)), "ifl_prof_read")
+    return ms.value, n.value
 
 
 def check(rc: int, what: str):

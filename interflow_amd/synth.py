@@ -127,10 +127,13 @@ def synth_flow_state(seed: int = 0, L: int = N_LEVELS, K: int = K_STEPS, extra: 
 
 
 def synth_rrdb_state(seed: int = 0, nf: int = 64, nb: int = 23, gc: int = 32, in_nc: int = 3,
-                     out_nc: int = 3, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
+                     out_nc: int = 3, prefix: str = "", feat_gain: float = 1.0 / 12.0) -> "OrderedDict[str, np.ndarray]":
     """State dict of the conditioning encoder `RRDBNet` (reference RRDBNet_arch.py:48-77).
     Dense blocks: kaiming-normal * 0.1, zero bias (module_util.py:7-16); the other convs use
-    PyTorch's default U(+-1/sqrt(fan_in)) for weight and bias."""
+    PyTorch's default U(+-1/sqrt(fan_in)) for weight and bias.  With those initialisers the 23-block
+    trunk amplifies U[0,1) images to features of rms ~11-15, far from what a trained encoder feeds the
+    flow; `feat_gain` scales `conv_first` (the trunk is positively homogeneous: zero biases, LeakyReLU)
+    so that the 320-channel conditioning maps come out with rms ~1."""
     rng = np.random.default_rng([seed, 0xBDB])
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
 
@@ -140,6 +143,8 @@ def synth_rrdb_state(seed: int = 0, nf: int = 64, nb: int = 23, gc: int = 32, in
         sd[prefix + name + ".bias"] = _f32(rng.uniform(-bound, bound, cout))
 
     default_conv("conv_first", nf, in_nc * 16)
+    for suffix in (".weight", ".bias"):
+        sd[prefix + "conv_first" + suffix] = _f32(sd[prefix + "conv_first" + suffix].astype(np.float64) * feat_gain)
     for b in range(nb):
         for r in (1, 2, 3):
             for c in range(1, 6):

@@ -187,7 +187,14 @@ def main():
         api["xr_noise_ld"] = ldr.numpy()
         out = model.weighted_interpolate_image(t(lr2), t(lr4), 0.35, cond_gt=t(gt))
         api["wi_035"] = out.numpy()
-        out = model.interpolate_image(t(lr2), 2, t(lr4), 4, 2.6, cond_gt=t(gt))
+        # interpolate_image encodes with add_gt_noise=True (flow_model.py:186-187): the quantisation noise comes
+        # from torch.rand, so pin it to 0.5 (zero noise) for a reproducible fixture
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: torch.full(a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a, 0.5)
+        try:
+            out = model.interpolate_image(t(lr2), 2, t(lr4), 4, 2.6, cond_gt=t(gt))
+        finally:
+            torch.rand = real_rand
         api["interp_26"] = out.numpy()
         api["digest"] = np.array(digest)
         np.savez_compressed(os.path.join(HERE, "api64_seed0.npz"), **api)

@@ -33,6 +33,7 @@ def t(a):
 
 def close(a, b, rtol=2e-5, atol=2e-5):
     a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert np.isfinite(np.asarray(b)).all() and np.isfinite(a).all()
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
