@@ -117,24 +117,27 @@ def main():
         for _ in range(args.warmup):
             out = step()
         barrier()
-        hip.prof_enable(True)
+        # only the dominant kernel is timed inside the timed region (16 launches per step, 2 events each)
+        hip.prof_enable([hip.K_CONV1_ENC_L1])
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    z, ld, xr, ldr = out
-    err = float((xr - x).abs().max())
-    assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
-
-    # kernel timing (HIP events recorded on the launch stream during the timed region)
-    prof = {}
-    for name, kid in (("conv1_enc_l1", hip.K_CONV1_ENC_L1), ("conv1_enc_l2", hip.K_CONV1_ENC_L2),
-                      ("conv1_dec_l1", hip.K_CONV1_DEC_L1), ("conv1_dec_l2", hip.K_CONV1_DEC_L2),
-                      ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC)):
-        ms, n = hip.prof_read(kid)
-        prof[name] = (ms, n)
-    hip.prof_enable(False)
+        dom_ms, dom_n = hip.prof_read(hip.K_CONV1_ENC_L1)
+        hip.prof_enable([])
+        z, ld, xr, ldr = out
+        err = float((xr - x).abs().max())
+        assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
+        # per-kernel breakdown from ONE extra, untimed step with every kernel bracketed by events
+        names = (("conv1_enc_l1", hip.K_CONV1_ENC_L1), ("conv1_enc_l2", hip.K_CONV1_ENC_L2),
+                 ("conv1_dec_l1", hip.K_CONV1_DEC_L1), ("conv1_dec_l2", hip.K_CONV1_DEC_L2),
+                 ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
+        hip.prof_enable([k for _, k in names])
+        step()
+        torch.cuda.synchronize()
+        prof = {name: hip.prof_read(kid) for name, kid in names}
+        hip.prof_enable([])
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -145,7 +148,7 @@ def main():
         patches = world * B * args.steps
         value = patches / elapsed
         # dominant kernel: conv1 (both networks) of the encode pass at level 1 (C=12, 80x80 planes)
-        ms1, n1 = prof["conv1_enc_l1"]
+        ms1, n1 = dom_ms, dom_n
         px1 = (PATCH // 2) ** 2
         flops_launch = 2.0 * conv1_macs_per_pixel(12) * px1 * B
         avg_ms = ms1 / max(n1, 1)
@@ -168,8 +171,8 @@ def main():
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": n1, "flops_per_launch": flops_launch},
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
-            "conv1_all_tflops": total_conv1_flops * args.steps / (conv1_ms * 1e-3) / 1e12 if conv1_ms else None,
+            "kernels_ms_per_step": {k: v[0] for k, v in prof.items()},
+            "conv1_all_tflops": total_conv1_flops / (conv1_ms * 1e-3) / 1e12 if conv1_ms else None,
             "path_tflops": 213.1e9 * B * args.steps / elapsed / 1e12,
             "roundtrip_max_abs_err": err,
         }

@@ -120,8 +120,9 @@ int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb,
              int B, int64_t n_per_sample, void* stream);
 
 /* ---- opt-in kernel timing (no counterpart in the reference; measurement aid for bench.py) ----
- * While enabled, the flow drivers bracket each launch of the kernels below with a pair of HIP events
- * recorded on the caller's stream (events are created on demand: the "no allocation" rule above holds
+ * ifl_prof_enable(mask): bit i of `mask` turns timing on for kernel id i (an event pair costs a few
+ * microseconds of stream time per launch, so time only what you report).  While enabled, the flow
+ * drivers bracket each launch of those kernels with a pair of HIP events recorded on the caller's stream (events are created on demand: the "no allocation" rule above holds
  * only while timing is off).  ifl_prof_read synchronises on those events and returns the summed
  * duration and the number of launches of one kernel id; ifl_prof_enable(0) frees the events.       */
 enum {
@@ -133,7 +134,7 @@ enum {
     IFL_K_CONV3_DEC = 5,
     IFL_K_ANIC = 6
 };
-int ifl_prof_enable(int on);
+int ifl_prof_enable(int mask);
 int ifl_prof_read(int kernel_id, double* total_ms, int64_t* count);
 
 #ifdef __cplusplus

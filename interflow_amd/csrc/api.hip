@@ -22,12 +22,12 @@ extern "C" const char* ifl_last_error(void) { return g_err; }
 #include <vector>
 namespace {
 struct ProfRec { int id; hipEvent_t a, b; };
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;      // bit i set: time kernel id i
 std::vector<ProfRec> g_prof;
 struct ProfScope {
     hipStream_t st; hipEvent_t b = nullptr;
     ProfScope(int id, hipStream_t s) : st(s) {
-        if (!g_prof_on) return;
+        if (!((g_prof_mask >> id) & 1u)) return;
         ProfRec r{id, nullptr, nullptr};
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         (void)hipEventRecord(r.a, st);
@@ -38,13 +38,13 @@ struct ProfScope {
 };
 }  // namespace
 
-extern "C" int ifl_prof_enable(int on)
+extern "C" int ifl_prof_enable(int mask)
 {
-    if (!on) {
+    if (!mask) {
         for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         g_prof.clear();
     }
-    g_prof_on = on != 0;
+    g_prof_mask = (unsigned)mask;
     return 0;
 }
 

@@ -36,7 +36,7 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
     static_assert(PXW * NPART == IFL_MT, "tile size");
     constexpr int NT = PXW / 32;              // 32-pixel MFMA column tiles per wave
     constexpr int NETS = 4 / NPART;
-    __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * IFL_CS];
+    __shared__ __attribute__((aligned(16))) float lds[LD_SLOTS * 32 * IFL_CS];   // >= IFL_PP_MAX pixels: staging stores need no bound test
 
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;                    // uniform for the whole workgroup
@@ -64,14 +64,16 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
     }
 
     // ---- patch staging: per-thread source offsets are the same for every chunk -----------------
+    // Slots past the patch read the plane's first float4 (valid memory) and land in LDS rows nobody reads, so the
+    // loads and stores below carry no branches.
     const float* ft_b = ftP + (int64_t)b * (g.H + 2) * W2 * IFL_FT;
-    int srcoff[LD_SLOTS];  // float offset of this thread's float4 inside the batch's ringed plane (chunk 0); -1 = none
+    int srcoff[LD_SLOTS];  // float offset of this thread's float4 inside the batch's ringed plane (chunk 0)
 #pragma unroll
     for (int i = 0; i < LD_SLOTS; ++i) {
         int idx = tid + i * 256;
         int p = idx >> 3, q = idx & 7;
         int r = p / t.PW, c = p - r * t.PW;
-        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_FT + q * 4) : -1;
+        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_FT + q * 4) : 0;
     }
 
     f32x16 acc[2][NT];
@@ -82,40 +84,63 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const float* w1 = prm + off.w1[net] + lane * 4;
+    // Weights: wave-uniform base (SGPR) + per-lane 32-bit offset.  They stream through a register ring WD k-steps
+    // deep, so each global load has WD * 16 * NT MFMAs of cover (the blocks of consecutive k-steps are contiguous in
+    // memory, also across chunk boundaries; the last prefetches read a little past the field, inside the block).
+    constexpr int WD = 3;
+    constexpr int ITERS = 36;                 // 9 taps x 4 k-steps of 8 channels per chunk
+    static_assert(ITERS % WD == 0, "ring slots must be compile-time");
+    const float* wnet = prm + off.w1[net];
+    const unsigned lane4 = lane * 4;
+    f32x4 wq[WD][2];
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wq[d][m] = *(const f32x4*)(wnet + (d * 2 + m) * 256 + lane4);
+
+    f32x4 stage[LD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)(ft_b + srcoff[i]);
 
     // ---- conditioning-feature part: K = 9 taps x 320 channels -----------------------------------
     for (int cc = 0; cc < NCC; ++cc) {
-        f32x4 stage[LD_SLOTS];
-#pragma unroll
-        for (int i = 0; i < LD_SLOTS; ++i)
-            if (srcoff[i] >= 0) stage[i] = *(const f32x4*)(ft_b + srcoff[i] + cc * IFL_CK);
         __syncthreads();                      // everyone finished reading the previous chunk
 #pragma unroll
         for (int i = 0; i < LD_SLOTS; ++i) {
             int idx = tid + i * 256;
-            if (srcoff[i] >= 0) *(f32x4*)&lds[(idx >> 3) * IFL_CS + (idx & 7) * 4] = stage[i];
+            *(f32x4*)&lds[(idx >> 3) * IFL_CS + (idx & 7) * 4] = stage[i];
         }
         __syncthreads();
-        const float* wc = w1 + (int64_t)cc * (9 * 4 * 2 * 256);
+        if (cc + 1 < NCC) {                   // next chunk's patch travels while this one is multiplied
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4);
+            for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)(ft_b + srcoff[i] + (cc + 1) * IFL_CK);
+        }
+        const float* wc = wnet + (int64_t)cc * (ITERS * 2 * 256);
+        // Software pipeline, pinned with sched_barrier so hipcc keeps it: while k-step `it` multiplies, the LDS
+        // reads of k-step it+1 and the weight loads of k-step it+WD are in flight.
+        f32x4 xb[2][NT];
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                f32x4 wa[2], xb[NT];
+        for (int n = 0; n < NT; ++n) xb[0][n] = *(const f32x4*)((const char*)lds + a0[n]);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) wa[m] = *(const f32x4*)(wc + ((tap * 4 + kq) * 2 + m) * 256);
+        for (int it = 0; it < ITERS; ++it) {
+            if (it + 1 < ITERS) {
+                const int tap = (it + 1) >> 2, kq = (it + 1) & 3;
+                const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    xb[n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + kq * 32);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
+                    xb[(it + 1) & 1][n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + kq * 32);
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = mfma32(wq[it % WD][m][e], xb[it & 1][n][e], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                wq[it % WD][m] = *(const f32x4*)(wc + ((it + WD) * 2 + m) * 256 + lane4);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -134,7 +159,7 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
         }
         __syncthreads();
         if (net == 0) {
-            const float* wz = w1 + (int64_t)NCC * (9 * 4 * 2 * 256);
+            const float* wz = wnet + (int64_t)NCC * (9 * 4 * 2 * 256) + lane4;
             const int nkq = KZ / 8;
             int az[NT];
 #pragma unroll

@@ -87,8 +87,12 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
 K_CONV1_ENC_L1, K_CONV1_ENC_L2, K_CONV1_DEC_L1, K_CONV1_DEC_L2, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
 
-def prof_enable(on: bool):
-    check(lib().ifl_prof_enable(1 if on else 0), "ifl_prof_enable")
+def prof_enable(kernel_ids=()):
+    """Time the given kernel ids (K_*) with HIP events; an empty list turns timing off and frees the events."""
+    mask = 0
+    for k in kernel_ids:
+        mask |= 1 << k
+    check(lib().ifl_prof_enable(mask), "ifl_prof_enable")
 
 
 def prof_read(kernel_id: int):
