@@ -118,20 +118,20 @@ def main():
             out = step()
         barrier()
         # only the dominant kernel is timed inside the timed region (16 launches per step, 2 events each)
-        hip.prof_enable([hip.K_CONV1_ENC_L1])
+        hip.prof_enable([hip.K_CONV1_FT_L1])
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
-        dom_ms, dom_n = hip.prof_read(hip.K_CONV1_ENC_L1)
+        dom_ms, dom_n = hip.prof_read(hip.K_CONV1_FT_L1)
         hip.prof_enable([])
         z, ld, xr, ldr = out
         err = float((xr - x).abs().max())
         assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
         # per-kernel breakdown from ONE extra, untimed step with every kernel bracketed by events
-        names = (("conv1_enc_l1", hip.K_CONV1_ENC_L1), ("conv1_enc_l2", hip.K_CONV1_ENC_L2),
-                 ("conv1_dec_l1", hip.K_CONV1_DEC_L1), ("conv1_dec_l2", hip.K_CONV1_DEC_L2),
+        names = (("conv1_ft_l1", hip.K_CONV1_FT_L1), ("conv1_ft_l2", hip.K_CONV1_FT_L2),
+                 ("conv1_finish", hip.K_CONV1_FINISH),
                  ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
         hip.prof_enable([k for _, k in names])
         step()
@@ -147,17 +147,16 @@ def main():
     if rank == 0:
         patches = world * B * args.steps
         value = patches / elapsed
-        # dominant kernel: conv1 (both networks) of the encode pass at level 1 (C=12, 80x80 planes)
+        # dominant kernel: conv1_ft_kernel at level 1 (C=12, 80x80 planes): the conditioning part of both coupling
+        # networks' first conv (+ fFeatures' 1x1).  Per step and pixel: 2 x 64*9*320 + 64*64 MACs.
         ms1, n1 = dom_ms, dom_n
         px1 = (PATCH // 2) ** 2
-        flops_launch = 2.0 * conv1_macs_per_pixel(12) * px1 * B
+        macs_px = 2 * 64 * 9 * 320 + 64 * 64
+        flops_l1_per_pass = 2.0 * macs_px * px1 * B * 16            # 16 conditional steps
+        flops_total = flops_l1_per_pass * 2 * args.steps          # encode + decode
+        flops_launch = flops_total / max(n1, 1)
         avg_ms = ms1 / max(n1, 1)
-        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if n1 else None
-        total_conv1_flops = 0.0
-        for lvl, C in ((1, 12), (2, 48)):
-            px = (PATCH >> lvl) ** 2
-            total_conv1_flops += 2 * 16 * 2.0 * conv1_macs_per_pixel(C) * px * B     # 16 steps, encode + decode
-        conv1_ms = sum(prof[k][0] for k in ("conv1_enc_l1", "conv1_enc_l2", "conv1_dec_l1", "conv1_dec_l2"))
+        achieved = flops_total / (ms1 * 1e-3) / 1e12 if n1 else None
         res = {
             "metric": "flow fwd+inv patches/sec (160x160, fp32)",
             "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,12 +166,11 @@ def main():
                                    "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
                                    "add_gt_noise=False (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)"},
-            "roofline": {"bound": "mfma", "kernel": "conv1_kernel<64,2> (coupling-network 3x3+1x1 convs, level 1, encode)",
+            "roofline": {"bound": "mfma", "kernel": "conv1_ft_kernel (coupling networks' first 3x3 conv over the 320 conditioning channels + 1x1, level 1)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": n1, "flops_per_launch": flops_launch},
             "kernels_ms_per_step": {k: v[0] for k, v in prof.items()},
-            "conv1_all_tflops": total_conv1_flops / (conv1_ms * 1e-3) / 1e12 if conv1_ms else None,
             "path_tflops": 213.1e9 * B * args.steps / elapsed / 1e12,
             "roundtrip_max_abs_err": err,
         }

@@ -126,10 +126,10 @@ int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb,
  * only while timing is off).  ifl_prof_read synchronises on those events and returns the summed
  * duration and the number of launches of one kernel id; ifl_prof_enable(0) frees the events.       */
 enum {
-    IFL_K_CONV1_ENC_L1 = 0,   /* conv1, both networks, level 1 (C = 12) */
-    IFL_K_CONV1_ENC_L2 = 1,   /* conv1, both networks, level 2 (C = 48) */
-    IFL_K_CONV1_DEC_L1 = 2,   /* conv1, one network per launch, level 1 */
-    IFL_K_CONV1_DEC_L2 = 3,
+    IFL_K_CONV1_FT_L1 = 0,    /* conv1_ft_kernel (conditioning part of both networks), level 1 (C = 12) */
+    IFL_K_CONV1_FT_L2 = 1,    /* same, level 2 (C = 48) */
+    IFL_K_CONV1_FINISH = 2,   /* conv1_finish_kernel (fAffine's z1 taps + epilogue) */
+    IFL_K_RESERVED = 3,
     IFL_K_CONV3_ENC = 4,
     IFL_K_CONV3_DEC = 5,
     IFL_K_ANIC = 6

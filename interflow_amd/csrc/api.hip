@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -129,7 +130,8 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         int64_t ring = (int64_t)B * (lv.H + 2) * (lv.W + 2);
         lv.ft = take(ring * IFL_FT);
         lv.z = take(ring * lv.C);
-        lv.h2 = take(ring * IFL_H2);
+        lv.h2_step = ring * IFL_H2;
+        lv.h2 = take(lv.h2_step * IFL_MAX_COND);
         lv.geom = choose_geom(lv.H, lv.W);
         slots += 2 * 16 * lv.geom.ntiles;
     }
@@ -184,8 +186,9 @@ extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const flo
 }
 
 // ---- one FlowStep on a level's ringed buffers -------------------------------------------------------------------
-static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int& slots,
-                       double& constant, float eps, hipStream_t st)
+// `h2` is the step's slab of hidden activations; its conditioning-only part (phase 1, conv1_ft_kernel) is already there.
+static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, float* h2,
+                       int& slots, double& constant, float eps, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
@@ -195,35 +198,31 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
     if (L.kind == 2) {
-        { ProfScope ps(lv.C == 12 ? IFL_K_CONV1_ENC_L1 : IFL_K_CONV1_ENC_L2, st);
-          rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 2, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_ENC, st);
-          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
+          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
     return 0;
 }
 
-static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int& slots,
-                       double& constant, float eps, hipStream_t st)
+static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, float* h2,
+                       int& slots, double& constant, float eps, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
     int rc;
     if (L.kind == 2) {
-        const int kid = lv.C == 12 ? IFL_K_CONV1_DEC_L1 : IFL_K_CONV1_DEC_L2;
-        { ProfScope ps(kid, st); rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 1, st); }
-        if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
+          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
-        { ProfScope ps(kid, st); rc = ifl_k_conv1(lv.ft, lv.z, lv.h2, prm, off, lv.geom, w.B, L.C, 0, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(lv.h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
+          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
@@ -252,6 +251,223 @@ static int check_layers(const ifl_layer* layers, int n_layers)
     return 0;
 }
 
+// ---- stream plan ------------------------------------------------------------------------------------------------------
+// A call is split into two kinds of work (DESIGN.md "schedule"):
+//   phase 1  conv1_ft_kernel: the z-independent ~98 % of the FLOPs, for all conditional steps, launched in chunks of
+//            IFL_P1_CHUNK steps on an auxiliary stream in the order the chain will need them;
+//   chain    everything that depends on the running z (ActNorm+1x1, fAffine's z1 taps, the last conv + coupling), step by
+//            step.  A step waits (event) for the phase-1 chunk that holds its slab, so the light, latency-bound chain
+//            runs underneath the next heavy chunk instead of leaving the chip idle between small kernels.
+// Samples are independent: the chain may further be cut into contiguous sample groups, each on its
+// own stream, forked from and joined back to the caller's stream with events.
+// The auxiliary streams and events are created once per device on first use and kept for the life of the process.
+#define IFL_MAX_GROUPS 4
+#define IFL_P1_CHUNK 4
+namespace {
+constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
+struct ForkCtx {
+    bool ok = false;
+    hipStream_t aux, s[IFL_MAX_GROUPS - 1];
+    hipEvent_t fork, aux_done, join[IFL_MAX_GROUPS - 1], p1[MAX_P1_EVENTS];
+};
+ForkCtx g_fork[64];
+
+int fork_ctx(ForkCtx** out)
+{
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    IFL_CHECK_ARG(dev >= 0 && dev < 64, IFL_ENOTSUP, "device index %d", dev);
+    ForkCtx& f = g_fork[dev];
+    if (!f.ok) {
+        int lo = 0, hi = 0;
+        IFL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent
+        IFL_HIP(hipStreamCreateWithPriority(&f.aux, hipStreamNonBlocking, lo));
+        for (int i = 0; i < IFL_MAX_GROUPS - 1; ++i) {
+            IFL_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
+            IFL_HIP(hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming));
+        }
+        for (int i = 0; i < MAX_P1_EVENTS; ++i) IFL_HIP(hipEventCreateWithFlags(&f.p1[i], hipEventDisableTiming));
+        IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+        IFL_HIP(hipEventCreateWithFlags(&f.aux_done, hipEventDisableTiming));
+        f.ok = true;
+    }
+    *out = &f;
+    return 0;
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+int n_groups(int B)
+{
+    static int forced = env_int("IFL_GROUPS", 1);
+    int g = forced;
+    if (g > IFL_MAX_GROUPS) g = IFL_MAX_GROUPS;
+    if (g > B) g = B;
+    return g < 1 ? 1 : g;
+}
+
+IflWs ws_slice(const IflWs& w, int b0, int nb)
+{
+    IflWs s = w;
+    s.B = nb;
+    for (int l = 0; l < IFL_MAX_LEVELS; ++l) {
+        IflLevelWs& lv = s.lv[l];
+        int64_t ring = (int64_t)b0 * (lv.H + 2) * (lv.W + 2);
+        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2;     // h2_step stays the full-batch slab stride
+    }
+    s.ldpart += (int64_t)b0 * w.ld_slots;
+    return s;
+}
+
+// the conditional steps of each level, in layer order
+struct CondPlan { int n[IFL_MAX_LEVELS]; IflStepList list[IFL_MAX_LEVELS]; int slab_of_layer[256]; };
+
+int make_plan(const ifl_layer* layers, int n_layers, CondPlan* p)
+{
+    IFL_CHECK_ARG(n_layers <= 256, IFL_ENOTSUP, "more than 256 layers");
+    int lvl = -1;
+    for (int l = 0; l < IFL_MAX_LEVELS; ++l) p->n[l] = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        p->slab_of_layer[i] = -1;
+        if (layers[i].kind == 0) ++lvl;
+        else if (layers[i].kind == 2) {
+            p->slab_of_layer[i] = p->n[lvl];
+            p->list[lvl].off[p->n[lvl]++] = layers[i].param_off;
+        }
+    }
+    return 0;
+}
+
+// phase 1 of one level: chunks of IFL_P1_CHUNK steps in the order given by `reverse`; event e0 + chunk index marks each
+int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* params, bool reverse, hipStream_t st,
+                  hipEvent_t* ev)
+{
+    const IflLevelWs& lv = w.lv[lvl];
+    const int n = plan.n[lvl];
+    static int chunk = env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK);
+    IflStepOff off = ifl_step_off(lv.C, 1);
+    const int nchunks = ifl_cdiv(n, chunk);
+    for (int c = 0; c < nchunks; ++c) {
+        const int ci = reverse ? nchunks - 1 - c : c;             // chunk holding the steps the chain needs next
+        const int s0 = ci * chunk, s1 = s0 + chunk < n ? s0 + chunk : n;
+        IflStepList sub{};
+        for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
+        int rc;
+        { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, st); }
+        if (rc) return rc;
+        if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
+    }
+    return 0;
+}
+
+int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float* params, const CondPlan& plan,
+                const IflWs& w, const float* src, float* dst, const float* logdet_in, float* logdet_out, float eps,
+                hipStream_t st, hipEvent_t* ev)
+{
+    const int B = w.B, H = w.H, W = w.W;
+    static int chunk = env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK);
+    int rc = 0, slots = 0;
+    double constant = 0.0;
+    int waited[IFL_MAX_LEVELS][IFL_MAX_COND] = {};
+    auto wait_slab = [&](int lvl, int slab) -> int {
+        if (!ev) return 0;
+        const int ci = slab / chunk;
+        if (!waited[lvl][ci]) { IFL_HIP(hipStreamWaitEvent(st, ev[lvl * IFL_MAX_COND + ci], 0)); waited[lvl][ci] = 1; }
+        return 0;
+    };
+    if (!decode) {
+        int lvl = -1;
+        for (int i = 0; i < n_layers; ++i) {
+            const ifl_layer& L = layers[i];
+            if (L.kind == 0) {
+                ++lvl;
+                if (lvl == 0) rc = ifl_k_squeeze_in(src, w.lv[0].z, B, 3, H, W, st);
+                else rc = ifl_k_squeeze_ring(w.lv[lvl - 1].z, w.lv[lvl].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
+            } else {
+                const int slab = plan.slab_of_layer[i];
+                if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
+                rc = step_encode(L, params, w, w.lv[lvl], w.lv[lvl].h2 + (int64_t)(slab < 0 ? 0 : slab) * w.lv[lvl].h2_step,
+                                 slots, constant, eps, st);
+            }
+            if (rc) return rc;
+        }
+        const IflLevelWs& last = w.lv[lvl];
+        if ((rc = ifl_k_ring_to_nchw(last.z, dst, B, last.C, last.H, last.W, st))) return rc;
+    } else {
+        int lvl = IFL_MAX_LEVELS - 1;
+        const IflLevelWs& last = w.lv[lvl];
+        if ((rc = ifl_k_nchw_to_ring(src, last.z, B, last.C, last.H, last.W, st))) return rc;
+        for (int i = n_layers - 1; i >= 0; --i) {
+            const ifl_layer& L = layers[i];
+            if (L.kind == 0) {
+                if (lvl == 0) rc = ifl_k_unsqueeze_out(w.lv[0].z, dst, B, 3, H, W, st);
+                else rc = ifl_k_unsqueeze_ring(w.lv[lvl].z, w.lv[lvl - 1].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
+                --lvl;
+            } else {
+                const int slab = plan.slab_of_layer[i];
+                if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
+                rc = step_decode(L, params, w, w.lv[lvl], w.lv[lvl].h2 + (int64_t)(slab < 0 ? 0 : slab) * w.lv[lvl].h2_step,
+                                 slots, constant, eps, st);
+            }
+            if (rc) return rc;
+        }
+    }
+    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
+}
+
+int run_flow(bool decode, const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src,
+             float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps, hipStream_t st)
+{
+    IflWs w;
+    ifl_ws_layout(ws, B, H, W, &w);
+    CondPlan plan;
+    int rc = make_plan(layers, n_layers, &plan);
+    if (rc) return rc;
+    static int use_aux = env_int("IFL_AUX_STREAM", 1);
+    const int G = n_groups(B);
+    const int64_t n_img = (int64_t)3 * H * W, n_lat = (int64_t)48 * (H / 4) * (W / 4);
+    const int64_t n_src = decode ? n_lat : n_img, n_dst = decode ? n_img : n_lat;
+    ForkCtx* f = nullptr;
+    hipEvent_t* ev = nullptr;
+    if (use_aux || G > 1) {
+        if ((rc = fork_ctx(&f))) return rc;
+        IFL_HIP(hipEventRecord(f->fork, st));
+    }
+    if (use_aux) {
+        ev = f->p1;
+        IFL_HIP(hipStreamWaitEvent(f->aux, f->fork, 0));
+    }
+    hipStream_t p1s = use_aux ? f->aux : st;
+    // phase 1 in the order the chain consumes the levels
+    for (int k = 0; k < IFL_MAX_LEVELS; ++k) {
+        const int lvl = decode ? IFL_MAX_LEVELS - 1 - k : k;
+        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev))) return rc;
+    }
+    if (use_aux) IFL_HIP(hipEventRecord(f->aux_done, f->aux));
+    else if (G > 1) IFL_HIP(hipEventRecord(f->fork, st));        // groups start after phase 1 on the caller's stream
+    for (int g = 0; g < G; ++g) {
+        const int b0 = (int)((int64_t)B * g / G), b1 = (int)((int64_t)B * (g + 1) / G);
+        hipStream_t sg = g == 0 ? st : f->s[g - 1];
+        if (g > 0) IFL_HIP(hipStreamWaitEvent(sg, f->fork, 0));
+        IflWs wg = ws_slice(w, b0, b1 - b0);
+        const float* li = logdet_in ? logdet_in + b0 : nullptr;
+        if ((rc = chain_group(decode, layers, n_layers, params, plan, wg, src + b0 * n_src, dst + b0 * n_dst, li,
+                              logdet_out + b0, eps, sg, ev))) return rc;
+        if (g > 0) {
+            IFL_HIP(hipEventRecord(f->join[g - 1], sg));
+            IFL_HIP(hipStreamWaitEvent(st, f->join[g - 1], 0));
+        }
+    }
+    if (use_aux) IFL_HIP(hipStreamWaitEvent(st, f->aux_done, 0));     // also joins when no step waited on phase 1
+    return 0;
+}
+}  // namespace
+
 extern "C" int ifl_flow_encode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
                                const float* x, float* z, const float* logdet_in, float* logdet_out,
                                int B, int H, int W, float eps, void* stream)
@@ -260,25 +476,7 @@ extern "C" int ifl_flow_encode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    IflWs w;
-    ifl_ws_layout(ws, B, H, W, &w);
-    int lvl = -1, slots = 0;
-    double constant = 0.0;
-    for (int i = 0; i < n_layers; ++i) {
-        const ifl_layer& L = layers[i];
-        if (L.kind == 0) {
-            ++lvl;
-            if (lvl == 0) rc = ifl_k_squeeze_in(x, w.lv[0].z, B, 3, H, W, st);
-            else rc = ifl_k_squeeze_ring(w.lv[lvl - 1].z, w.lv[lvl].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
-        } else {
-            rc = step_encode(L, params, w, w.lv[lvl], slots, constant, eps, st);
-        }
-        if (rc) return rc;
-    }
-    const IflLevelWs& last = w.lv[lvl];
-    if ((rc = ifl_k_ring_to_nchw(last.z, z, B, last.C, last.H, last.W, st))) return rc;
-    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
+    return run_flow(false, layers, n_layers, params, ws, x, z, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -289,25 +487,7 @@ extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    IflWs w;
-    ifl_ws_layout(ws, B, H, W, &w);
-    int lvl = IFL_MAX_LEVELS - 1, slots = 0;
-    double constant = 0.0;
-    const IflLevelWs& last = w.lv[lvl];
-    if ((rc = ifl_k_nchw_to_ring(z, last.z, B, last.C, last.H, last.W, st))) return rc;
-    for (int i = n_layers - 1; i >= 0; --i) {
-        const ifl_layer& L = layers[i];
-        if (L.kind == 0) {
-            if (lvl == 0) rc = ifl_k_unsqueeze_out(w.lv[0].z, x, B, 3, H, W, st);
-            else rc = ifl_k_unsqueeze_ring(w.lv[lvl].z, w.lv[lvl - 1].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
-            --lvl;
-        } else {
-            rc = step_decode(L, params, w, w.lv[lvl], slots, constant, eps, st);
-        }
-        if (rc) return rc;
-    }
-    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
+    return run_flow(true, layers, n_layers, params, ws, z, x, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* ws, const float* z_in, float* z_out,
@@ -331,8 +511,15 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
     if (layer->kind == 2 && (rc = ifl_k_nchw_to_ring(ft, lv.ft, B, IFL_FT, lv.H, lv.W, st))) return rc;
     int slots = 0;
     double constant = 0.0;
-    rc = reverse ? step_decode(*layer, params, w, lv, slots, constant, eps, st)
-                 : step_encode(*layer, params, w, lv, slots, constant, eps, st);
+    if (layer->kind == 2) {
+        IflStepList one{};
+        one.off[0] = layer->param_off;
+        { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, st); }
+        if (rc) return rc;
+    }
+    rc = reverse ? step_decode(*layer, params, w, lv, lv.h2, slots, constant, eps, st)
+                 : step_encode(*layer, params, w, lv, lv.h2, slots, constant, eps, st);
     if (rc) return rc;
     if ((rc = ifl_k_ring_to_nchw(lv.z, z_out, B, lv.C, lv.H, lv.W, st))) return rc;
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);

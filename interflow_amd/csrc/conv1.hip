@@ -18,6 +18,15 @@
 // follow the accumulator's channel order) -- no LDS transpose between the two GEMMs.
 #include "ifl_common.h"
 
+// Two kernels (DESIGN.md "conv1"):
+//   conv1_ft_kernel      the z-independent bulk: the 9 x 320-channel conditioning part of BOTH networks' first conv for
+//                        EVERY conditional step of a level in one launch (grid.z = step).  fFeatures is finished here
+//                        (ActNorm, ReLU, 1x1, ActNorm, ReLU -> h2[..][64:128]); fAffine's 64 raw pre-activation sums go
+//                        to h2[..][0:64].  ~98 % of the path's FLOPs, no dependence on the running z, so one launch per
+//                        level fills the chip without a partly filled last round per step.
+//   conv1_finish_kernel  per step, in the sequential chain: fAffine's remaining K = 9 x C/2 taps over z1 are added to
+//                        the stored sums, then its ActNorm, ReLU, 1x1, ActNorm, ReLU -> h2[..][0:64].
+
 namespace {
 
 constexpr int NCC = IFL_FT / IFL_CK;          // 10 chunks of 32 conditioning channels
@@ -27,47 +36,118 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// PXW: pixels per wave (32 or 64).  NPART: pixel parts per workgroup; nets per workgroup = 4 / NPART.
-template <int PXW, int NPART>
-__global__ __launch_bounds__(256, 2)
-void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, float* __restrict__ h2P,
-                  const float* __restrict__ prm, IflStepOff off, IflGeom g, int C, int net0)
+// this lane's pixels of the tile: LDS byte address of the top-left tap (+16*h) and ring pixel index (or -1)
+template <int NT>
+__device__ __forceinline__ void lane_pixels(const IflTile& t, const IflGeom& g, int b, int first, int j, int h, int cs,
+                                            int (&a0)[NT], int64_t (&opix)[NT])
 {
-    static_assert(PXW * NPART == IFL_MT, "tile size");
-    constexpr int NT = PXW / 32;              // 32-pixel MFMA column tiles per wave
-    constexpr int NETS = 4 / NPART;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int idx = t.s + first + n * 32 + j;
+        bool valid = idx < t.npx;
+        int idc = valid ? idx : t.npx - 1;
+        int ty = idc / t.bwb, tx = idc - ty * t.bwb;
+        a0[n] = (((ty - t.y_first - 1) * t.PW + tx) * cs + 4 * h) * 4;
+        opix[n] = valid ? ((int64_t)(b * (g.H + 2) + ty + 1) * (g.W + 2) + t.x0 + tx + 1) : -1;
+    }
+}
+
+// ActNorm + ReLU on a 64-channel x (NT*32)-pixel accumulator block (flow.py:60-64, FlowActNorms.py:87-92), then the
+// 1x1 conv 64 -> 64 straight from the accumulators (the 32x32 C/D layout has the pixel on the lane and the channel in
+// the register index, and the 1x1 weights are packed in that channel order), its ActNorm + ReLU, and the store.
+// Accumulator element (m, r) of lane (j, h) is channel m*32 + (r&3) + 8*(r>>2) + 4*h; the ActNorm tables are stored in
+// that order: an[0/1 = bias/scale][m][h][r].
+template <int NT>
+__device__ __forceinline__ void finish_and_store(f32x16 (&acc)[2][NT], const float* __restrict__ an1,
+                                                 const float* __restrict__ w2, const float* __restrict__ an2,
+                                                 float* __restrict__ h2net, const int64_t (&opix)[NT], int lane, int h)
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4 bb[4], ss[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bb[q] = *(const f32x4*)(an1 + (m * 2 + h) * 16 + q * 4);
+            ss[q] = *(const f32x4*)(an1 + 64 + (m * 2 + h) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[m][n][r] + bb[r >> 2][r & 3]) * ss[r >> 2][r & 3];
+                acc[m][n][r] = v > 0.f ? v : 0.f;
+            }
+    }
+    const float* w2l = w2 + lane * 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x16 y[2];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[m2][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 wv[2];
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) wv[m2] = *(const f32x4*)(w2l + ((m2 * 2 + m) * 4 + gq) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma32(wv[m2][e], acc[m][n][gq * 4 + e], y[m2]);
+            }
+        if (opix[n] >= 0) {
+            float* dst = h2net + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 bb = *(const f32x4*)(an2 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 ss = *(const f32x4*)(an2 + 64 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (y[m2][gq * 4 + e] + bb[e]) * ss[e];
+                        o[e] = v > 0.f ? v : 0.f;
+                    }
+                    *(f32x4*)(dst + m2 * 32 + gq * 8) = o;
+                }
+        }
+    }
+}
+
+// ---- phase 1: conditioning part of both networks, all steps of a level --------------------------------------------
+// 4 waves = 2 networks x 2 pixel halves of the 128-pixel tile; each wave owns 64 output channels x 64 pixels.
+__global__ __launch_bounds__(256, 2)
+void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
+                     const float* __restrict__ params, IflStepList steps, IflStepOff off, IflGeom g)
+{
+    constexpr int NT = 2;
     __shared__ __attribute__((aligned(16))) float lds[LD_SLOTS * 32 * IFL_CS];   // >= IFL_PP_MAX pixels: staging stores need no bound test
 
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;                    // uniform for the whole workgroup
     const int b = blockIdx.y;
+    const float* prm = params + steps.off[blockIdx.z];
+    float* h2P = h2all + (int64_t)blockIdx.z * h2_step_stride;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int net = (NETS == 2) ? (wave & 1) : net0;
-    const int part = (NETS == 2) ? (wave >> 1) : wave;
+    const int net = wave & 1, part = wave >> 1;
     const int W2 = g.W + 2;
-    const int KZ = ifl_kz(C);
 
-    // ---- this lane's pixels -------------------------------------------------------------------
-    int a0[NT];            // LDS byte address of the pixel's top-left tap, + 16*h
-    int64_t opix[NT];      // ring pixel index of the output pixel (or -1 when past the band's end)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        int idx = t.s + part * PXW + n * 32 + j;
-        bool valid = idx < t.npx;
-        int idc = valid ? idx : t.npx - 1;
-        int ty = idc / t.bwb, tx = idc - ty * t.bwb;
-        a0[n] = (((ty - t.y_first - 1) * t.PW + tx) * IFL_CS + 4 * h) * 4;
-        opix[n] = valid ? ((int64_t)(b * (g.H + 2) + ty + 1) * W2 + t.x0 + tx + 1) : -1;
-    }
+    int a0[NT];
+    int64_t opix[NT];
+    lane_pixels<NT>(t, g, b, part * 64, j, h, IFL_CS, a0, opix);
 
     // ---- patch staging: per-thread source offsets are the same for every chunk -----------------
     // Slots past the patch read the plane's first float4 (valid memory) and land in LDS rows nobody reads, so the
     // loads and stores below carry no branches.
     const float* ft_b = ftP + (int64_t)b * (g.H + 2) * W2 * IFL_FT;
-    int srcoff[LD_SLOTS];  // float offset of this thread's float4 inside the batch's ringed plane (chunk 0)
+    int srcoff[LD_SLOTS];
 #pragma unroll
     for (int i = 0; i < LD_SLOTS; ++i) {
         int idx = tid + i * 256;
@@ -84,9 +164,9 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // Weights: wave-uniform base (SGPR) + per-lane 32-bit offset.  They stream through a register ring WD k-steps
-    // deep, so each global load has WD * 16 * NT MFMAs of cover (the blocks of consecutive k-steps are contiguous in
-    // memory, also across chunk boundaries; the last prefetches read a little past the field, inside the block).
+    // Weights: wave-uniform base + per-lane offset.  They stream through a register ring WD k-steps deep, so each global
+    // load has WD * 16 MFMAs of cover (the blocks of consecutive k-steps are contiguous in memory, also across chunk
+    // boundaries; the last prefetches read a little past the field, inside the step's block).
     constexpr int WD = 3;
     constexpr int ITERS = 36;                 // 9 taps x 4 k-steps of 8 channels per chunk
     static_assert(ITERS % WD == 0, "ring slots must be compile-time");
@@ -102,7 +182,6 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
 #pragma unroll
     for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)(ft_b + srcoff[i]);
 
-    // ---- conditioning-feature part: K = 9 taps x 320 channels -----------------------------------
     for (int cc = 0; cc < NCC; ++cc) {
         __syncthreads();                      // everyone finished reading the previous chunk
 #pragma unroll
@@ -144,122 +223,111 @@ void conv1_kernel(const float* __restrict__ ftP, const float* __restrict__ zP, f
         }
     }
 
-    // ---- z1 part (fAffine only): K = 9 taps x KZ channels (C/2 padded to a multiple of 8 with zero weights) --
-    const bool wg_has_a = (NETS == 2) || (net0 == 0);
-    if (wg_has_a) {
-        const int CSZ = KZ + 4;               // 12 or 28 words: CSZ/4 odd
-        const int nq = KZ / 4;                // float4 per pixel
-        const float* z_b = zP + (int64_t)b * (g.H + 2) * W2 * C;
-        __syncthreads();
-        for (int idx = tid; idx < t.PP * nq; idx += 256) {
-            int p = idx / nq, q = idx - p * nq;
-            int r = p / t.PW, c = p - r * t.PW;
-            f32x4 v = *(const f32x4*)(z_b + (int64_t)((t.y_first + 1 + r) * W2 + t.x0 + c) * C + q * 4);
-            *(f32x4*)&lds[p * CSZ + q * 4] = v;
+    if (net == 0) {
+        // fAffine: raw sums, finished by conv1_finish_kernel once z1 of this step exists
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (opix[n] < 0) continue;
+            float* dst = h2P + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(f32x4*)(dst + m * 32 + gq * 8) = f32x4{acc[m][n][gq * 4], acc[m][n][gq * 4 + 1],
+                                                             acc[m][n][gq * 4 + 2], acc[m][n][gq * 4 + 3]};
         }
-        __syncthreads();
-        if (net == 0) {
-            const float* wz = wnet + (int64_t)NCC * (9 * 4 * 2 * 256) + lane4;
-            const int nkq = KZ / 8;
-            int az[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) az[n] = (a0[n] - 16 * h) / IFL_CS * CSZ + 16 * h;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (CSZ * 4);
-                for (int kq = 0; kq < nkq; ++kq) {
-                    f32x4 wa[2], xb[NT];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) wa[m] = *(const f32x4*)(wz + ((tap * nkq + kq) * 2 + m) * 256);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        xb[n] = *(const f32x4*)((const char*)lds + az[n] + tapoff + kq * 32);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
-                }
-            }
-        }
+    } else {
+        finish_and_store<NT>(acc, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
     }
+}
 
-    // ---- ActNorm + ReLU on the 64 x PXW accumulator block (flow.py:60-64, FlowActNorms.py:87-92) -------------
-    // accumulator element (m, r) of lane (j, h) is channel m*32 + (r&3) + 8*(r>>2) + 4*h; the tables are stored
-    // in that order: an[0/1 = bias/scale][m][h][r].
-    {
-        const float* an = prm + off.an1[net];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f32x4 bb[4], ss[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bb[q] = *(const f32x4*)(an + (m * 2 + h) * 16 + q * 4);
-                ss[q] = *(const f32x4*)(an + 64 + (m * 2 + h) * 16 + q * 4);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[m][n][r] + bb[r >> 2][r & 3]) * ss[r >> 2][r & 3];
-                    acc[m][n][r] = v > 0.f ? v : 0.f;
-                }
-        }
+// ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
+// 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
+// of 8 with zero weights).
+__global__ __launch_bounds__(256, 2)
+void conv1_finish_kernel(const float* __restrict__ zP, float* __restrict__ h2P, const float* __restrict__ prm,
+                         IflStepOff off, IflGeom g, int C)
+{
+    constexpr int NT = 1;
+    __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * 28];
+    const IflTile t = ifl_tile(g, blockIdx.x);
+    if (!t.active) return;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int W2 = g.W + 2;
+    const int KZ = ifl_kz(C);
+    const int CSZ = KZ + 4;                   // 12 or 28 words: CSZ/4 odd => conflict-free b128 reads
+    const int nq = KZ / 4;
+
+    int a0[NT];
+    int64_t opix[NT];
+    lane_pixels<NT>(t, g, b, wave * 32, j, h, CSZ, a0, opix);
+
+    const float* z_b = zP + (int64_t)b * (g.H + 2) * W2 * C;
+    for (int idx = tid; idx < t.PP * nq; idx += 256) {
+        int p = idx / nq, q = idx - p * nq;
+        int r = p / t.PW, c = p - r * t.PW;
+        f32x4 v = *(const f32x4*)(z_b + (int64_t)((t.y_first + 1 + r) * W2 + t.x0 + c) * C + q * 4);
+        *(f32x4*)&lds[p * CSZ + q * 4] = v;
     }
-
-    // ---- 1x1 conv 64 -> 64 straight from the accumulators, then ActNorm + ReLU, then store --------------------
-    const float* w2 = prm + off.w2[net] + lane * 4;
-    const float* an2 = prm + off.an2[net];
+    // accumulators start from the stored conditioning-part sums
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        f32x16 y[2];
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[m2][r] = 0.f;
+        const float* src = h2P + (opix[n] >= 0 ? opix[n] : 0) * IFL_H2 + 4 * h;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                f32x4 wv[2];
+                f32x4 v = *(const f32x4*)(src + m * 32 + gq * 8);
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) wv[m2] = *(const f32x4*)(w2 + ((m2 * 2 + m) * 4 + gq) * 256);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma32(wv[m2][e], acc[m][n][gq * 4 + e], y[m2]);
+                for (int e = 0; e < 4; ++e) acc[m][n][gq * 4 + e] = v[e];
             }
-        if (opix[n] >= 0) {
-            float* dst = h2P + opix[n] * IFL_H2 + net * IFL_HID + 4 * h;
+    }
+    __syncthreads();
+    const float* wz = prm + off.w1[0] + (int64_t)NCC * (9 * 4 * 2 * 256) + lane * 4;
+    const int nkq = KZ / 8;
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (CSZ * 4);
+        for (int kq = 0; kq < nkq; ++kq) {
+            f32x4 wa[2], xb[NT];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    f32x4 bb = *(const f32x4*)(an2 + (m2 * 2 + h) * 16 + gq * 4);
-                    f32x4 ss = *(const f32x4*)(an2 + 64 + (m2 * 2 + h) * 16 + gq * 4);
-                    f32x4 o;
+            for (int m = 0; m < 2; ++m) wa[m] = *(const f32x4*)(wz + ((tap * nkq + kq) * 2 + m) * 256);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = (y[m2][gq * 4 + e] + bb[e]) * ss[e];
-                        o[e] = v > 0.f ? v : 0.f;
-                    }
-                    *(f32x4*)(dst + m2 * 32 + gq * 8) = o;
-                }
+            for (int n = 0; n < NT; ++n)
+                xb[n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + kq * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
         }
     }
+    finish_and_store<NT>(acc, prm + off.an1[0], prm + off.w2[0], prm + off.an2[0], h2P, opix, lane, h);
 }
 
 }  // namespace
 
-int ifl_k_conv1(const float* ft, const float* z, float* h2, const float* prm, const IflStepOff& off,
-                const IflGeom& g, int B, int C, int nets, hipStream_t st)
+int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, hipStream_t st)
+{
+    if (nsteps <= 0) return 0;
+    dim3 grid(g.ntiles, B, nsteps), block(256);
+    hipLaunchKernelGGL(conv1_ft_kernel, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_conv1_finish(const float* z, float* h2, const float* prm, const IflStepOff& off, const IflGeom& g, int B,
+                       int C, hipStream_t st)
 {
     dim3 grid(g.ntiles, B), block(256);
-    if (nets == 2)
-        hipLaunchKernelGGL((conv1_kernel<64, 2>), grid, block, 0, st, ft, z, h2, prm, off, g, C, 0);
-    else
-        hipLaunchKernelGGL((conv1_kernel<32, 4>), grid, block, 0, st, ft, z, h2, prm, off, g, C, nets);
+    hipLaunchKernelGGL(conv1_finish_kernel, grid, block, 0, st, z, h2, prm, off, g, C);
     IFL_LAUNCH_CHECK();
     return 0;
 }

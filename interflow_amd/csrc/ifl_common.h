@@ -90,13 +90,17 @@ static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_couplin
     return o;
 }
 
+#define IFL_MAX_COND 16       // conditional steps per level (flow_model.py:42 K=16)
+struct IflStepList { int64_t off[IFL_MAX_COND]; };     // float offsets of the steps' parameter blocks
+
 // ---- workspace layout -----------------------------------------------------------------------------
 struct IflLevelWs {
     int H, W;                 // plane size at this level
     int C;                    // z channels
     float* ft;                // [B][H+2][W+2][320]  zero ring
     float* z;                 // [B][H+2][W+2][C]    zero ring
-    float* h2;                // [B][H+2][W+2][128]  zero ring
+    float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step
+    int64_t h2_step;          // floats per step slab
     IflGeom geom;
 };
 
@@ -132,9 +136,11 @@ int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float lo
                float* out, int B, int C, int HW, hipStream_t st);
 int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B,
                int64_t n, hipStream_t st);
-// conv1.hip:  nets: 0 = fAffine only, 1 = fFeatures only, 2 = both
-int ifl_k_conv1(const float* ft, const float* z, float* h2, const float* prm, const IflStepOff& off,
-                const IflGeom& g, int B, int C, int nets, hipStream_t st);
+// conv1.hip
+int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, hipStream_t st);
+int ifl_k_conv1_finish(const float* z, float* h2, const float* prm, const IflStepOff& off, const IflGeom& g, int B,
+                       int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine
 int ifl_k_conv3(const float* h2, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
                 const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st);

@@ -84,7 +84,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read")
 
-K_CONV1_ENC_L1, K_CONV1_ENC_L2, K_CONV1_DEC_L1, K_CONV1_DEC_L2, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
+K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
 
 def prof_enable(kernel_ids=()):
