@@ -94,6 +94,17 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
                     const float* z, float* x, const float* logdet_in, float* logdet_out,
                     int B, int H, int W, float eps, void* stream);
 
+/* How ifl_flow_encode / ifl_flow_decode spread their work over streams (no counterpart in the reference).
+ *   aux_stream      1: the z-independent bulk convolutions run on a library-owned low-priority stream, forked from and
+ *                   joined to the caller's stream with events, so the per-step chain overlaps them; 0: everything is
+ *                   enqueued on the caller's stream in order.
+ *   groups          1..4 contiguous sample groups whose chains run on separate library-owned streams.
+ *   p1_chunk_steps  conditional steps per bulk launch (1..16).
+ * A negative / zero value keeps the current setting.  Defaults: 1, 2, 4 (environment IFL_AUX_STREAM, IFL_GROUPS,
+ * IFL_P1_CHUNK_STEPS override them at load).  Results do not depend on the schedule.  The library-owned streams and
+ * events are created once per device at the first call that needs them.                                            */
+int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps);
+
 /* ---- stand-alone operators on NCHW tensors ---- */
 /* squeeze2d / unsqueeze2d, flow.py:163-193 (pure index permutation, bit-exact). */
 int ifl_squeeze2d(const float* in, float* out, int B, int C, int H, int W, int factor, void* stream);

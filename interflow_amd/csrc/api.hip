@@ -301,10 +301,17 @@ int env_int(const char* name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
+// schedule knobs: defaults, overridable by the environment (read once) and by ifl_set_schedule()
+struct Sched { int aux, groups, chunk; };
+Sched& sched()
+{
+    static Sched s{env_int("IFL_AUX_STREAM", 1), env_int("IFL_GROUPS", 2), env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK)};
+    return s;
+}
+
 int n_groups(int B)
 {
-    static int forced = env_int("IFL_GROUPS", 1);
-    int g = forced;
+    int g = sched().groups;
     if (g > IFL_MAX_GROUPS) g = IFL_MAX_GROUPS;
     if (g > B) g = B;
     return g < 1 ? 1 : g;
@@ -348,7 +355,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
 {
     const IflLevelWs& lv = w.lv[lvl];
     const int n = plan.n[lvl];
-    static int chunk = env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK);
+    const int chunk = sched().chunk;
     IflStepOff off = ifl_step_off(lv.C, 1);
     const int nchunks = ifl_cdiv(n, chunk);
     for (int c = 0; c < nchunks; ++c) {
@@ -370,7 +377,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
                 hipStream_t st, hipEvent_t* ev)
 {
     const int B = w.B, H = w.H, W = w.W;
-    static int chunk = env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK);
+    const int chunk = sched().chunk;
     int rc = 0, slots = 0;
     double constant = 0.0;
     int waited[IFL_MAX_LEVELS][IFL_MAX_COND] = {};
@@ -428,7 +435,7 @@ int run_flow(bool decode, const ifl_layer* layers, int n_layers, const float* pa
     CondPlan plan;
     int rc = make_plan(layers, n_layers, &plan);
     if (rc) return rc;
-    static int use_aux = env_int("IFL_AUX_STREAM", 1);
+    const int use_aux = sched().aux;
     const int G = n_groups(B);
     const int64_t n_img = (int64_t)3 * H * W, n_lat = (int64_t)48 * (H / 4) * (W / 4);
     const int64_t n_src = decode ? n_lat : n_img, n_dst = decode ? n_img : n_lat;
@@ -467,6 +474,17 @@ int run_flow(bool decode, const ifl_layer* layers, int n_layers, const float* pa
     return 0;
 }
 }  // namespace
+
+extern "C" int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps)
+{
+    IFL_CHECK_ARG(groups <= IFL_MAX_GROUPS && p1_chunk_steps <= IFL_MAX_COND, IFL_EINVAL,
+                  "groups <= %d, chunk <= %d", IFL_MAX_GROUPS, IFL_MAX_COND);
+    Sched& s = sched();
+    if (aux_stream >= 0) s.aux = aux_stream != 0;
+    if (groups >= 1) s.groups = groups;
+    if (p1_chunk_steps >= 1) s.chunk = p1_chunk_steps;
+    return 0;
+}
 
 extern "C" int ifl_flow_encode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
                                const float* x, float* z, const float* logdet_in, float* logdet_out,

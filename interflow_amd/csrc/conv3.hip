@@ -29,6 +29,47 @@ __device__ __forceinline__ float scale_of(float h, float eps) {
 
 enum { MODE_ENC = 0, MODE_DEC_F = 1, MODE_DEC_A = 2 };
 
+// One 32-channel chunk of one network: 9 taps x 2 k-steps of 16 channels, NTL output tiles x 2 pixel tiles.
+// Pinned software pipeline (sched_barrier): while k-step `it` multiplies, the LDS reads of it+1 and the weight loads of
+// it+WD are in flight; WD is deeper when few tiles give each k-step little MFMA time to hide a global load.
+template <int NTL>
+__device__ __forceinline__ void chunk_mma(f32x4 (&acc)[NTL][2], const float* __restrict__ w3l, int half,
+                                          const float* lds, const int (&a0)[2], int PW)
+{
+    constexpr int ITERS = 18;
+    constexpr int WD = NTL >= 6 ? 1 : (NTL >= 3 ? 2 : (NTL == 2 ? 3 : 6));
+    static_assert(ITERS % WD == 0, "ring slots must be compile-time");
+    f32x4 wq[WD][NTL], xb[2][2];
+    auto wptr = [&](int it, int i) { return w3l + ((i * 9 + (it >> 1)) * 4 + half * 2 + (it & 1)) * 256; };
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) wq[d][i] = *(const f32x4*)wptr(d, i);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) xb[0][n] = *(const f32x4*)((const char*)lds + a0[n]);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        if (it + 1 < ITERS) {
+            const int tap = (it + 1) >> 1, s2 = (it + 1) & 1;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * (IFL_CS3 * 4);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                xb[(it + 1) & 1][n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + s2 * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[i][n] = mfma16(wq[it % WD][i][e], xb[it & 1][n][e], acc[i][n]);
+        if (it + WD < ITERS) {
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) wq[it % WD][i] = *(const f32x4*)wptr(it + WD, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NF, int NA, int MODE>
 __global__ __launch_bounds__(256, 2)
 void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots,
@@ -38,7 +79,7 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
     constexpr bool DO_A = (MODE == MODE_ENC || MODE == MODE_DEC_A);
     constexpr bool DO_F = (MODE == MODE_ENC || MODE == MODE_DEC_F);
     constexpr int NAA = DO_A ? NA : 1, NFF = DO_F ? NF : 1;
-    __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * IFL_CS3];
+    __shared__ __attribute__((aligned(16))) float lds[LDP * 32 * IFL_CS3];   // >= IFL_PP_MAX pixels: branch-free staging
     __shared__ float red[4];
 
     const IflTile t = ifl_tile(g, blockIdx.x);
@@ -72,7 +113,7 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
         int idx = tid + i * 256;
         int p = idx >> 3, qq = idx & 7;
         int r = p / t.PW, c = p - r * t.PW;
-        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_H2 + qq * 4) : -1;
+        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_H2 + qq * 4) : 0;
     }
 
     f32x4 accA[NAA][2], accF[NFF][2];
@@ -87,52 +128,26 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
 
     // chunk = 32 hidden channels: chunks 0,1 belong to fAffine, 2,3 to fFeatures
     constexpr int CH0 = DO_A ? 0 : 2, CH1 = DO_F ? 4 : 2;
+    f32x4 stage[LDP];
+#pragma unroll
+    for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)(h2_b + srcoff[i] + CH0 * IFL_CK);
 #pragma unroll
     for (int ch = CH0; ch < CH1; ++ch) {
         const int net = ch >> 1, half = ch & 1;
-        f32x4 stage[LDP];
-#pragma unroll
-        for (int i = 0; i < LDP; ++i)
-            if (srcoff[i] >= 0) stage[i] = *(const f32x4*)(h2_b + srcoff[i] + ch * IFL_CK);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LDP; ++i) {
             int idx = tid + i * 256;
-            if (srcoff[i] >= 0) *(f32x4*)&lds[(idx >> 3) * IFL_CS3 + (idx & 7) * 4] = stage[i];
+            *(f32x4*)&lds[(idx >> 3) * IFL_CS3 + (idx & 7) * 4] = stage[i];
         }
         __syncthreads();
-        const float* w3 = prm + off.w3[net] + lane * 4;
+        if (ch + 1 < CH1) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS3 * 4);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                f32x4 xb[2];
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    xb[n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + s2 * 64);
-                const int sidx = half * 2 + s2;
-                if (net == 0) {
-#pragma unroll
-                    for (int i = 0; i < NAA; ++i) {
-                        f32x4 w = *(const f32x4*)(w3 + ((i * 9 + tap) * 4 + sidx) * 256);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) accA[i][n] = mfma16(w[e], xb[n][e], accA[i][n]);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NFF; ++i) {
-                        f32x4 w = *(const f32x4*)(w3 + ((i * 9 + tap) * 4 + sidx) * 256);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) accF[i][n] = mfma16(w[e], xb[n][e], accF[i][n]);
-                    }
-                }
-            }
+            for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)(h2_b + srcoff[i] + (ch + 1) * IFL_CK);
         }
+        const float* w3 = prm + off.w3[net] + lane * 4;
+        if (net == 0) chunk_mma<NAA>(accA, w3, half, lds, a0, t.PW);
+        else chunk_mma<NFF>(accF, w3, half, lds, a0, t.PW);
     }
 
     // ---- epilogue: Conv2dZeros bias/scale, sigmoid, coupling, log-det ------------------------------------------

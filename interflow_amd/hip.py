@@ -68,6 +68,8 @@ def lib():
     L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    L.ifl_set_schedule.argtypes = [c_int, c_int, c_int]
+    L.ifl_set_schedule.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -82,9 +84,14 @@ def lib():
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
-           "ifl_prof_enable", "ifl_prof_read")
+           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
+
+
+def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -1):
+    """Stream plan of the flow drivers (see ifl_set_schedule in interflow_hip.h); -1 keeps a setting."""
+    check(lib().ifl_set_schedule(aux_stream, groups, p1_chunk_steps), "ifl_set_schedule")
 
 
 def prof_enable(kernel_ids=()):
