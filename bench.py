@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true",
+                    help="after the timed region also run the steps on one stream and time every kernel (extra fields)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,45 +115,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prof, serial = {}, None
     with torch.no_grad():
         for _ in range(args.warmup):
             out = step()
         barrier()
-        # only the dominant kernel is timed inside the timed region (8 launches per step, 2 events each)
+        # only the dominant kernel is timed inside the timed region: an event pair around each of its 8 launches per
+        # step, recorded on the stream the kernel is launched on (the library's auxiliary stream by default)
         hip.prof_enable([hip.K_CONV1_FT_L1])
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
-        conc_ms, conc_n = hip.prof_read(hip.K_CONV1_FT_L1)
-        hip.prof_enable([])
-        # The default schedule overlaps the bulk kernel with the light per-step chain on other streams, so its launch
-        # durations in the timed region include time-sharing the CUs with those kernels.  For the roofline figure the
-        # same steps are repeated with everything on one stream (kernels strictly one after another).
-        hip.set_schedule(aux_stream=0, groups=1)
-        step(); torch.cuda.synchronize()
-        hip.prof_enable([hip.K_CONV1_FT_L1])
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        serial_elapsed = time.perf_counter() - t1
         dom_ms, dom_n = hip.prof_read(hip.K_CONV1_FT_L1)
         hip.prof_enable([])
         z, ld, xr, ldr = out
         err = float((xr - x).abs().max())
         assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
-        # per-kernel breakdown from ONE extra, untimed step with every kernel bracketed by events
-        names = (("conv1_ft_l1", hip.K_CONV1_FT_L1), ("conv1_ft_l2", hip.K_CONV1_FT_L2),
-                 ("conv1_finish", hip.K_CONV1_FINISH),
-                 ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
-        hip.prof_enable([k for _, k in names])
-        step()
-        torch.cuda.synchronize()
-        prof = {name: hip.prof_read(kid) for name, kid in names}
-        hip.prof_enable([])
-        hip.set_schedule(aux_stream=1, groups=2)
+        if args.breakdown:
+            # (1) the same steps with everything on ONE stream: kernels strictly one after another, so the dominant
+            #     kernel's duration is free of time-sharing with the per-step chain; (2) one step with every kernel timed
+            hip.set_schedule(aux_stream=0, groups=1)
+            step(); torch.cuda.synchronize()
+            hip.prof_enable([hip.K_CONV1_FT_L1])
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            serial_elapsed = time.perf_counter() - t1
+            s_ms, s_n = hip.prof_read(hip.K_CONV1_FT_L1)
+            hip.prof_enable([])
+            serial = {"ms_per_step": serial_elapsed / args.steps * 1e3, "dominant_avg_launch_ms": s_ms / max(s_n, 1)}
+            names = (("conv1_ft_l1", hip.K_CONV1_FT_L1), ("conv1_ft_l2", hip.K_CONV1_FT_L2),
+                     ("conv1_finish", hip.K_CONV1_FINISH),
+                     ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
+            hip.prof_enable([k for _, k in names])
+            step()
+            torch.cuda.synchronize()
+            prof = {name: hip.prof_read(kid) for name, kid in names}
+            hip.prof_enable([])
+            hip.set_schedule(aux_stream=1, groups=2)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -161,16 +165,22 @@ def main():
     if rank == 0:
         patches = world * B * args.steps
         value = patches / elapsed
-        # dominant kernel: conv1_ft_kernel at level 1 (C=12, 80x80 planes): the conditioning part of both coupling
-        # networks' first conv (+ fFeatures' 1x1).  Per step and pixel: 2 x 64*9*320 + 64*64 MACs.
+        # dominant kernel: conv1_ft_kernel<1> (level 1: C=12, 80x80 planes): the conditioning part of both coupling
+        # networks' first conv (+ fFeatures' 1x1).  Algorithmic work per conditional step and pixel:
+        # 2 x 64*9*320 + 64*64 MACs (SURVEY.md section 8(a) row a11 without the z1 taps, fAffine's 1x1 and the last conv).
         ms1, n1 = dom_ms, dom_n
         px1 = (PATCH // 2) ** 2
         macs_px = 2 * 64 * 9 * 320 + 64 * 64
-        flops_l1_per_pass = 2.0 * macs_px * px1 * B * 16            # 16 conditional steps
-        flops_total = flops_l1_per_pass * 2 * args.steps          # encode + decode
+        flops_total = 2.0 * macs_px * px1 * B * 16 * 2 * args.steps     # 16 conditional steps, encode + decode
         flops_launch = flops_total / max(n1, 1)
         avg_ms = ms1 / max(n1, 1)
-        achieved = flops_total / (ms1 * 1e-3) / 1e12 if n1 else None
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if n1 else None
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and B == BATCH:
+            tj = json.load(open(tpath)).get("conv1_ft_kernel<1>")
+            if tj:
+                traffic, traffic_note = tj["bytes_per_launch"], tj["note"]
         res = {
             "metric": "flow fwd+inv patches/sec (160x160, fp32)",
             "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,18 +190,23 @@ def main():
                                    "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
                                    "add_gt_noise=False (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)"},
-            "roofline": {"bound": "mfma", "kernel": "conv1_ft_kernel (coupling networks' first 3x3 conv over the 320 conditioning channels + 1x1, level 1)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv1_ft_kernel<1> (both coupling networks' first 3x3 conv over the 320 conditioning "
+                                   "channels + fFeatures' 1x1, level 1, 4 conditional steps per launch)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
                          "avg_launch_ms": avg_ms, "launches": n1, "flops_per_launch": flops_launch,
-                         "method": "HIP events around every launch of this kernel, same steps re-run on ONE stream "
-                                   "(ms_per_step %.2f); inside the timed region (overlapped with the per-step chain on "
-                                   "other streams) the same launches average %.3f ms" % (
-                                       serial_elapsed / args.steps * 1e3, conc_ms / max(conc_n, 1))},
-            "kernels_ms_per_step": {k: v[0] for k, v in prof.items()},
+                         "method": "HIP event pair around every launch of this kernel inside the timed region, on the "
+                                   "stream it is launched on; the light per-step chain runs concurrently on other "
+                                   "streams, so the duration includes sharing the CUs with it (--breakdown re-times it alone)"},
             "path_tflops": 213.1e9 * B * args.steps / elapsed / 1e12,
             "roundtrip_max_abs_err": err,
         }
+        if serial:
+            res["serial_schedule"] = serial
+            res["serial_schedule"]["dominant_tflops_alone"] = flops_launch / (serial["dominant_avg_launch_ms"] * 1e-3) / 1e12
+            res["kernels_ms_per_step"] = {k: v[0] for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(res), flush=True)

@@ -365,7 +365,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
         for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
         int rc;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, st); }
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, lvl + 1, st); }
         if (rc) return rc;
         if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
     }
@@ -533,7 +533,7 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
         IflStepList one{};
         one.off[0] = layer->param_off;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, st); }
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, lvl + 1, st); }
         if (rc) return rc;
     }
     rc = reverse ? step_decode(*layer, params, w, lv, lv.h2, slots, constant, eps, st)

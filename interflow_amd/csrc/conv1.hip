@@ -120,6 +120,8 @@ __device__ __forceinline__ void finish_and_store(f32x16 (&acc)[2][NT], const flo
 
 // ---- phase 1: conditioning part of both networks, all steps of a level --------------------------------------------
 // 4 waves = 2 networks x 2 pixel halves of the 128-pixel tile; each wave owns 64 output channels x 64 pixels.
+// LVL (1 or 2) only names the instantiation, so that a profile lists the two flow levels separately.
+template <int LVL>
 __global__ __launch_bounds__(256, 2)
 void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
                      const float* __restrict__ params, IflStepList steps, IflStepOff off, IflGeom g)
@@ -314,11 +316,12 @@ void conv1_finish_kernel(const float* __restrict__ zP, float* __restrict__ h2P, 
 }  // namespace
 
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
-                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, hipStream_t st)
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, hipStream_t st)
 {
     if (nsteps <= 0) return 0;
     dim3 grid(g.ntiles, B, nsteps), block(256);
-    hipLaunchKernelGGL(conv1_ft_kernel, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+    if (level == 1) hipLaunchKernelGGL(conv1_ft_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+    else hipLaunchKernelGGL(conv1_ft_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
     IFL_LAUNCH_CHECK();
     return 0;
 }

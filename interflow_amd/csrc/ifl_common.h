@@ -138,7 +138,7 @@ int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* w
                int64_t n, hipStream_t st);
 // conv1.hip
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
-                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, hipStream_t st);
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, float* h2, const float* prm, const IflStepOff& off, const IflGeom& g, int B,
                        int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine
