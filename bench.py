@@ -25,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from interflow_amd import hip, synth  # noqa: E402
+from interflow_amd import hip, shard, synth  # noqa: E402
 from interflow_amd.flow_model import InterpFlow  # noqa: E402
 
 PATCH = 160
@@ -77,20 +77,14 @@ def main():
                     help="after the timed region also run the steps on one stream and time every kernel (extra fields)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = shard.dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dist = shard.init_dist("nccl", dev)            # RCCL; only the barrier and the max-over-ranks clock use it
 
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)
     model = InterpFlow(SCALES)
@@ -110,10 +104,7 @@ def main():
         return z, ld, xr, ldr
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(dist, dev)
 
     prof, serial = {}, None
     with torch.no_grad():
@@ -157,10 +148,7 @@ def main():
             hip.prof_enable([])
             hip.set_schedule(aux_stream=1, groups=2)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
     if rank == 0:
         patches = world * B * args.steps

@@ -94,6 +94,24 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
                     const float* z, float* x, const float* logdet_in, float* logdet_out,
                     int B, int H, int W, float eps, void* stream);
 
+/* Conditioning reuse.  Both coupling networks of a step start with a 3x3 conv over the 320 conditioning channels
+ * (FlowAffineCouplingsAblation.py:219-233); that part -- 93 % of the path's FLOPs -- depends only on rrdbResults and the
+ * weights, not on the tensor flowing through the stack.  The reference recomputes it in every pass; its own callers run
+ * several passes over one conditioning (weighted_interpolate_image, flow_model.py:194-200: two encodes and one decode;
+ * generate_images.py:60-81: 19 weights per image; train.py:73,85-86,94: three encodes and one decode share lr_enc).
+ * ifl_cond_prepare computes that part once for every conditional step into the workspace (after ifl_load_cond of both
+ * levels); ifl_flow_pass with IFL_FLOW_COND_PREPARED then runs only the part of the stack that depends on the running
+ * tensor.  The prepared state lives in `ws` and stays valid until ifl_load_cond, ifl_flow_encode/decode (which prepare
+ * on their own), ifl_flow_step or ifl_ws_init touch that workspace, or the parameters change.  Results are identical,
+ * bit for bit, to ifl_flow_encode / ifl_flow_decode (same kernels, same order of operations).
+ * ifl_flow_pass(decode = 0/1, flags = 0) is ifl_flow_encode / ifl_flow_decode.                                      */
+#define IFL_FLOW_COND_PREPARED 1
+int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
+                     void* stream);
+int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src, float* dst,
+                  const float* logdet_in, float* logdet_out, int B, int H, int W, float eps, int decode, int flags,
+                  void* stream);
+
 /* How ifl_flow_encode / ifl_flow_decode spread their work over streams (no counterpart in the reference).
  *   aux_stream      1: the z-independent bulk convolutions run on a library-owned low-priority stream, forked from and
  *                   joined to the caller's stream with events, so the per-step chain overlaps them; 0: everything is
@@ -129,6 +147,10 @@ int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, f
  * wa/wb are per-sample weights in device memory, n_per_sample = C*H*W.                          */
 int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,
              int B, int64_t n_per_sample, void* stream);
+
+/* Image quantisation of the generation loop, generate_images.py:89-91:
+ * out[b,h,w,c] = (uint8)(clip(x[b,c,h,w], 0, 1) * 255)   (NCHW float32 -> NHWC uint8, bit-exact with numpy).  C in {1,3,4}. */
+int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);
 
 /* ---- opt-in kernel timing (no counterpart in the reference; measurement aid for bench.py) ----
  * ifl_prof_enable(mask): bit i of `mask` turns timing on for kernel id i (an event pair costs a few

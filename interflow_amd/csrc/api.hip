@@ -132,6 +132,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.z = take(ring * lv.C);
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
+        lv.ha = take(ring * IFL_HID);
         lv.geom = choose_geom(lv.H, lv.W);
         slots += 2 * 16 * lv.geom.ntiles;
     }
@@ -198,10 +199,10 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
     if (L.kind == 2) {
-        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, prm, off, lv.geom, w.B, L.C, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_ENC, st);
-          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
+          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
@@ -216,13 +217,13 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
     int rc;
     if (L.kind == 2) {
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
+          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
-        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, prm, off, lv.geom, w.B, L.C, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(h2, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
+          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
@@ -324,7 +325,7 @@ IflWs ws_slice(const IflWs& w, int b0, int nb)
     for (int l = 0; l < IFL_MAX_LEVELS; ++l) {
         IflLevelWs& lv = s.lv[l];
         int64_t ring = (int64_t)b0 * (lv.H + 2) * (lv.W + 2);
-        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2;     // h2_step stays the full-batch slab stride
+        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2; lv.ha += ring * IFL_HID;     // h2_step stays the full-batch slab stride
     }
     s.ldpart += (int64_t)b0 * w.ld_slots;
     return s;
@@ -351,11 +352,11 @@ int make_plan(const ifl_layer* layers, int n_layers, CondPlan* p)
 
 // phase 1 of one level: chunks of IFL_P1_CHUNK steps in the order given by `reverse`; event e0 + chunk index marks each
 int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* params, bool reverse, hipStream_t st,
-                  hipEvent_t* ev)
+                  hipEvent_t* ev, int chunk_override = 0)
 {
     const IflLevelWs& lv = w.lv[lvl];
     const int n = plan.n[lvl];
-    const int chunk = sched().chunk;
+    const int chunk = chunk_override > 0 ? chunk_override : sched().chunk;
     IflStepOff off = ifl_step_off(lv.C, 1);
     const int nchunks = ifl_cdiv(n, chunk);
     for (int c = 0; c < nchunks; ++c) {
@@ -427,15 +428,16 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
 }
 
-int run_flow(bool decode, const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src,
-             float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps, hipStream_t st)
+int run_flow(bool decode, bool prepared, const ifl_layer* layers, int n_layers, const float* params, void* ws,
+             const float* src, float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps,
+             hipStream_t st)
 {
     IflWs w;
     ifl_ws_layout(ws, B, H, W, &w);
     CondPlan plan;
     int rc = make_plan(layers, n_layers, &plan);
     if (rc) return rc;
-    const int use_aux = sched().aux;
+    const int use_aux = prepared ? 0 : sched().aux;     // prepared: phase 1 was run by ifl_cond_prepare, the slabs are ready
     const int G = n_groups(B);
     const int64_t n_img = (int64_t)3 * H * W, n_lat = (int64_t)48 * (H / 4) * (W / 4);
     const int64_t n_src = decode ? n_lat : n_img, n_dst = decode ? n_img : n_lat;
@@ -451,7 +453,7 @@ int run_flow(bool decode, const ifl_layer* layers, int n_layers, const float* pa
     }
     hipStream_t p1s = use_aux ? f->aux : st;
     // phase 1 in the order the chain consumes the levels
-    for (int k = 0; k < IFL_MAX_LEVELS; ++k) {
+    for (int k = 0; k < IFL_MAX_LEVELS && !prepared; ++k) {
         const int lvl = decode ? IFL_MAX_LEVELS - 1 - k : k;
         if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev))) return rc;
     }
@@ -494,7 +496,7 @@ extern "C" int ifl_flow_encode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    return run_flow(false, layers, n_layers, params, ws, x, z, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
+    return run_flow(false, false, layers, n_layers, params, ws, x, z, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -505,7 +507,36 @@ extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    return run_flow(true, layers, n_layers, params, ws, z, x, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
+    return run_flow(true, false, layers, n_layers, params, ws, z, x, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
+}
+
+extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
+                                void* stream)
+{
+    int rc = check_shape(B, H, W);
+    if (rc) return rc;
+    if ((rc = check_layers(layers, n_layers))) return rc;
+    IFL_CHECK_ARG(params && ws, IFL_EINVAL, "null pointer");
+    IflWs w;
+    ifl_ws_layout(ws, B, H, W, &w);
+    CondPlan plan;
+    if ((rc = make_plan(layers, n_layers, &plan))) return rc;
+    for (int lvl = 0; lvl < IFL_MAX_LEVELS; ++lvl)      // one launch per level: all conditional steps at once
+        if ((rc = launch_phase1(w, lvl, plan, params, false, (hipStream_t)stream, nullptr, IFL_MAX_COND))) return rc;
+    return 0;
+}
+
+extern "C" int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src,
+                             float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps,
+                             int decode, int flags, void* stream)
+{
+    int rc = check_shape(B, H, W);
+    if (rc) return rc;
+    if ((rc = check_layers(layers, n_layers))) return rc;
+    IFL_CHECK_ARG(params && ws && src && dst && logdet_out, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG((flags & ~IFL_FLOW_COND_PREPARED) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
+    return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, layers, n_layers, params, ws, src, dst, logdet_in,
+                    logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* ws, const float* z_in, float* z_out,
@@ -559,6 +590,14 @@ extern "C" int ifl_unsqueeze2d(const float* in, float* out, int B, int C, int H,
     IFL_CHECK_ARG(C % (factor * factor) == 0, IFL_EINVAL, "%d", C);                                     // flow.py:189
     IFL_CHECK_ARG((in && out) || (int64_t)B * C * H * W == 0, IFL_EINVAL, "null pointer");
     return ifl_k_squeeze_nchw(in, out, B, C / (factor * factor), H * factor, W * factor, factor, 1, (hipStream_t)stream);
+}
+
+extern "C" int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream)
+{
+    IFL_CHECK_ARG(B >= 0 && C >= 1 && H >= 0 && W >= 0, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG((x && out) || (int64_t)B * H * W == 0, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B <= 65535, IFL_ENOTSUP, "B=%d exceeds the grid's y extent", B);
+    return ifl_k_quantize_u8(x, out, B, C, (int64_t)H * W, (hipStream_t)stream);
 }
 
 extern "C" int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov,

@@ -25,7 +25,8 @@
 //                        to h2[..][0:64].  ~98 % of the path's FLOPs, no dependence on the running z, so one launch per
 //                        level fills the chip without a partly filled last round per step.
 //   conv1_finish_kernel  per step, in the sequential chain: fAffine's remaining K = 9 x C/2 taps over z1 are added to
-//                        the stored sums, then its ActNorm, ReLU, 1x1, ActNorm, ReLU -> h2[..][0:64].
+//                        the stored sums, then its ActNorm, ReLU, 1x1, ActNorm, ReLU -> ha (the slab keeps the raw sums,
+//                        so a prepared conditioning serves any number of passes: ifl_cond_prepare).
 
 namespace {
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ void lane_pixels(const IflTile& t, const IflGeom& g, 
 // the register index, and the 1x1 weights are packed in that channel order), its ActNorm + ReLU, and the store.
 // Accumulator element (m, r) of lane (j, h) is channel m*32 + (r&3) + 8*(r>>2) + 4*h; the ActNorm tables are stored in
 // that order: an[0/1 = bias/scale][m][h][r].
-template <int NT>
+template <int NT, int STRIDE>
 __device__ __forceinline__ void finish_and_store(f32x16 (&acc)[2][NT], const float* __restrict__ an1,
                                                  const float* __restrict__ w2, const float* __restrict__ an2,
                                                  float* __restrict__ h2net, const int64_t (&opix)[NT], int lane, int h)
@@ -99,7 +100,7 @@ __device__ __forceinline__ void finish_and_store(f32x16 (&acc)[2][NT], const flo
                     for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma32(wv[m2][e], acc[m][n][gq * 4 + e], y[m2]);
             }
         if (opix[n] >= 0) {
-            float* dst = h2net + opix[n] * IFL_H2 + 4 * h;
+            float* dst = h2net + opix[n] * STRIDE + 4 * h;
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
@@ -239,7 +240,7 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
                                                              acc[m][n][gq * 4 + 2], acc[m][n][gq * 4 + 3]};
         }
     } else {
-        finish_and_store<NT>(acc, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
+        finish_and_store<NT, IFL_H2>(acc, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
     }
 }
 
@@ -247,8 +248,8 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
 // 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
 // of 8 with zero weights).
 __global__ __launch_bounds__(256, 2)
-void conv1_finish_kernel(const float* __restrict__ zP, float* __restrict__ h2P, const float* __restrict__ prm,
-                         IflStepOff off, IflGeom g, int C)
+void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__ h2P, float* __restrict__ haP,
+                         const float* __restrict__ prm, IflStepOff off, IflGeom g, int C)
 {
     constexpr int NT = 1;
     __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * 28];
@@ -310,7 +311,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, float* __restrict__ h2P, 
                     for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
         }
     }
-    finish_and_store<NT>(acc, prm + off.an1[0], prm + off.w2[0], prm + off.an2[0], h2P, opix, lane, h);
+    finish_and_store<NT, IFL_HID>(acc, prm + off.an1[0], prm + off.w2[0], prm + off.an2[0], haP, opix, lane, h);
 }
 
 }  // namespace
@@ -326,11 +327,11 @@ int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const 
     return 0;
 }
 
-int ifl_k_conv1_finish(const float* z, float* h2, const float* prm, const IflStepOff& off, const IflGeom& g, int B,
-                       int C, hipStream_t st)
+int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
+                       const IflGeom& g, int B, int C, hipStream_t st)
 {
     dim3 grid(g.ntiles, B), block(256);
-    hipLaunchKernelGGL(conv1_finish_kernel, grid, block, 0, st, z, h2, prm, off, g, C);
+    hipLaunchKernelGGL(conv1_finish_kernel, grid, block, 0, st, z, h2, ha, prm, off, g, C);
     IFL_LAUNCH_CHECK();
     return 0;
 }

@@ -72,7 +72,7 @@ __device__ __forceinline__ void chunk_mma(f32x4 (&acc)[NTL][2], const float* __r
 
 template <int NF, int NA, int MODE>
 __global__ __launch_bounds__(256, 2)
-void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots,
+void conv3_kernel(const float* __restrict__ h2P, const float* __restrict__ haP, float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots,
                   int slot0, const float* __restrict__ prm, IflStepOff off, IflGeom g, int C, float eps)
 {
     constexpr int LDP = (IFL_PP_MAX * 8 + 255) / 256;
@@ -106,15 +106,20 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
         opix[n] = valid ? ((int64_t)(b * (g.H + 2) + ty + 1) * W2 + t.x0 + tx + 1) : -1;
     }
 
-    const float* h2_b = h2P + (int64_t)b * (g.H + 2) * W2 * IFL_H2;
-    int srcoff[LDP];
+    // staging sources: fAffine's activations come from `ha` (64 floats per pixel), fFeatures' from the step's slab
+    // (128 floats per pixel, upper half); slots past the patch read the plane's first pixel and land in unread LDS rows
+    const float* h2_b = h2P + (int64_t)b * (g.H + 2) * W2 * IFL_H2 + IFL_HID + (tid & 7) * 4;
+    const float* ha_b = haP + (int64_t)b * (g.H + 2) * W2 * IFL_HID + (tid & 7) * 4;
+    int srcpix[LDP];
 #pragma unroll
     for (int i = 0; i < LDP; ++i) {
-        int idx = tid + i * 256;
-        int p = idx >> 3, qq = idx & 7;
+        int p = (tid + i * 256) >> 3;
         int r = p / t.PW, c = p - r * t.PW;
-        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_H2 + qq * 4) : 0;
+        srcpix[i] = (p < t.PP) ? ((t.y_first + 1 + r) * W2 + t.x0 + c) : 0;
     }
+    auto src_of = [&](int ch, int i) -> const float* {       // ch is a compile-time constant at every call site
+        return (ch < 2) ? ha_b + srcpix[i] * IFL_HID + ch * IFL_CK : h2_b + srcpix[i] * IFL_H2 + (ch - 2) * IFL_CK;
+    };
 
     f32x4 accA[NAA][2], accF[NFF][2];
 #pragma unroll
@@ -130,7 +135,7 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
     constexpr int CH0 = DO_A ? 0 : 2, CH1 = DO_F ? 4 : 2;
     f32x4 stage[LDP];
 #pragma unroll
-    for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)(h2_b + srcoff[i] + CH0 * IFL_CK);
+    for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)src_of(CH0, i);
 #pragma unroll
     for (int ch = CH0; ch < CH1; ++ch) {
         const int net = ch >> 1, half = ch & 1;
@@ -143,7 +148,7 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
         __syncthreads();
         if (ch + 1 < CH1) {
 #pragma unroll
-            for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)(h2_b + srcoff[i] + (ch + 1) * IFL_CK);
+            for (int i = 0; i < LDP; ++i) stage[i] = *(const f32x4*)src_of(ch + 1, i);
         }
         const float* w3 = prm + off.w3[net] + lane * 4;
         if (net == 0) chunk_mma<NAA>(accA, w3, half, lds, a0, t.PW);
@@ -225,27 +230,27 @@ void conv3_kernel(const float* __restrict__ h2P, float* __restrict__ zP, float* 
 }
 
 template <int NF, int NA>
-int launch(const float* h2, float* z, float* ldpart, int ld_slots, int slot0, const float* prm, const IflStepOff& off,
+int launch(const float* h2, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm, const IflStepOff& off,
            const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st)
 {
     dim3 grid(g.ntiles, B), block(256);
     if (mode == MODE_ENC)
-        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_ENC>), grid, block, 0, st, h2, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
+        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_ENC>), grid, block, 0, st, h2, ha, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
     else if (mode == MODE_DEC_F)
-        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_DEC_F>), grid, block, 0, st, h2, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
+        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_DEC_F>), grid, block, 0, st, h2, ha, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
     else
-        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_DEC_A>), grid, block, 0, st, h2, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
+        hipLaunchKernelGGL((conv3_kernel<NF, NA, MODE_DEC_A>), grid, block, 0, st, h2, ha, z, ldpart, ld_slots, slot0, prm, off, g, C, eps);
     IFL_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-int ifl_k_conv3(const float* h2, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
+int ifl_k_conv3(const float* h2, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
                 const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st)
 {
-    if (C == 12) return launch<2, 1>(h2, z, ldpart, ld_slots, slot0, prm, off, g, B, C, mode, eps, st);
-    if (C == 48) return launch<6, 3>(h2, z, ldpart, ld_slots, slot0, prm, off, g, B, C, mode, eps, st);
+    if (C == 12) return launch<2, 1>(h2, ha, z, ldpart, ld_slots, slot0, prm, off, g, B, C, mode, eps, st);
+    if (C == 48) return launch<6, 3>(h2, ha, z, ldpart, ld_slots, slot0, prm, off, g, B, C, mode, eps, st);
     ifl_set_error("conv3: C=%d not supported (12 or 48)", C);
     return IFL_ENOTSUP;
 }

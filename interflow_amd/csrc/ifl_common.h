@@ -99,7 +99,9 @@ struct IflLevelWs {
     int C;                    // z channels
     float* ft;                // [B][H+2][W+2][320]  zero ring
     float* z;                 // [B][H+2][W+2][C]    zero ring
-    float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step
+    float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step: [0:64] fAffine's
+                              //   conditioning-only pre-activation sums, [64:128] fFeatures' finished hidden activations
+    float* ha;                // [B][H+2][W+2][64]  zero ring; fAffine's finished hidden activations of the step in flight
     int64_t h2_step;          // floats per step slab
     IflGeom geom;
 };
@@ -128,6 +130,7 @@ int ifl_k_unsqueeze_out(const float* zr, float* x, int B, int C, int H, int W, h
 int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hipStream_t st);                    // ringed [H,W,C] -> ringed [H/2,W/2,4C]
 int ifl_k_unsqueeze_ring(const float* b, float* a, int B, int C, int H, int W, hipStream_t st);
 int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, int f, int reverse, hipStream_t st);
+int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st);
 // pointwise.hip
 int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st);            // in place on ringed NHWC
 int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
@@ -139,8 +142,8 @@ int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* w
 // conv1.hip
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                    int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, hipStream_t st);
-int ifl_k_conv1_finish(const float* z, float* h2, const float* prm, const IflStepOff& off, const IflGeom& g, int B,
-                       int C, hipStream_t st);
+int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
+                       const IflGeom& g, int B, int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine
-int ifl_k_conv3(const float* h2, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
+int ifl_k_conv3(const float* h2, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
                 const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st);

@@ -124,7 +124,52 @@ void squeeze_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, 
     if (!reverse) out[e] = in[l]; else out[l] = in[e];
 }
 
+// ---- image quantisation for the generation loop: (clip(x, 0, 1) * 255) -> uint8, NCHW -> NHWC ---------------------------
+// generate_images.py:89-91: `(np.clip(output, 0., 1.0)*255).astype(np.uint8)` then `.transpose(0,2,3,1)`.
+// One thread per 4 consecutive pixels: C float4 loads (coalesced per channel plane), 4*C contiguous output bytes.
+template <int C>
+__global__ __launch_bounds__(256)
+void quantize_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t P, int64_t nquads)
+{
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * C * P;
+    uint8_t* ob = out + (int64_t)b * C * P;
+    for (int64_t qd = (int64_t)blockIdx.x * 256 + threadIdx.x; qd < nquads; qd += (int64_t)gridDim.x * 256) {
+        const int64_t p0 = qd * 4;
+        uint8_t v[4 * C];
+        if (p0 + 4 <= P && (P & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                f32x4 f = *(const f32x4*)(xb + c * P + p0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e * C + c] = (uint8_t)(fminf(fmaxf(f[e], 0.f), 1.f) * 255.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * C; ++i) ob[p0 * C + i] = v[i];
+        } else {
+            for (int64_t p = p0; p < P && p < p0 + 4; ++p)
+                for (int c = 0; c < C; ++c) ob[p * C + c] = (uint8_t)(fminf(fmaxf(xb[c * P + p], 0.f), 1.f) * 255.f);
+        }
+    }
+}
+
 }  // namespace
+
+int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st)
+{
+    if (B == 0 || P == 0) return 0;
+    int64_t nquads = (P + 3) / 4;
+    int gx = (int)((nquads + 255) / 256 < 4096 ? (nquads + 255) / 256 : 4096);
+    dim3 grid(gx, B), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL(quantize_u8_kernel<1>, grid, block, 0, st, x, out, P, nquads); break;
+        case 3: hipLaunchKernelGGL(quantize_u8_kernel<3>, grid, block, 0, st, x, out, P, nquads); break;
+        case 4: hipLaunchKernelGGL(quantize_u8_kernel<4>, grid, block, 0, st, x, out, P, nquads); break;
+        default: ifl_set_error("quantize_u8: C=%d not supported (1, 3 or 4)", C); return IFL_ENOTSUP;
+    }
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
 
 int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, hipStream_t st)
 {

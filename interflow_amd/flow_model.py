@@ -297,6 +297,7 @@ class InterpFlow(nn.Module):
         scale2 = torch.tensor(scale2).double()
         target_scale = torch.tensor(target_scale).double()
         lr_enc = self.arch.rrdbPreprocessing(cond_gt)          # computed once, the reference recomputes it 3 times
+        lr_enc = self.flow_upsampler.prepare_cond(lr_enc, input_lr1.shape[0], input_lr1.shape[2], input_lr1.shape[3])
         z1, _ = self.forward(input_lr1, cond_gt, lr_enc=lr_enc, calc_loss=False)
         z2, _ = self.forward(input_lr2, cond_gt, lr_enc=lr_enc, calc_loss=False)
         a = (target_scale - scale2) / (scale1 - scale2)
@@ -306,6 +307,7 @@ class InterpFlow(nn.Module):
 
     def weighted_interpolate_image(self, input_lr1, input_lr2, a, cond_gt, add_noise=False):
         lr_enc = self.arch.rrdbPreprocessing(cond_gt)
+        lr_enc = self.flow_upsampler.prepare_cond(lr_enc, input_lr1.shape[0], input_lr1.shape[2], input_lr1.shape[3])
         z1, _ = self.forward(input_lr1, cond_gt, lr_enc=lr_enc, add_gt_noise=add_noise, calc_loss=False)
         z2, _ = self.forward(input_lr2, cond_gt, lr_enc=lr_enc, add_gt_noise=add_noise, calc_loss=False)
         target_z = hip.lerp(z1, z2, 1 - a, a)

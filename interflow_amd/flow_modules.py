@@ -194,6 +194,7 @@ class FlowStep(nn.Module):
         params, layers = self._pack(z.device)
         lvl = 1 if C == 12 else 2
         ws = hip.Workspace.get(B, h << lvl, w << lvl, z.device)
+        ws.generation += 1                      # a prepared conditioning in this workspace is overwritten
         out = torch.empty_like(z)
         ld_in = None if logdet is None else _as_logdet(logdet, B, z.device)
         ld_out = torch.empty(B, dtype=torch.float32, device=z.device)
@@ -211,6 +212,23 @@ def _as_logdet(logdet, B, device):
         ld = logdet.to(device=device, dtype=torch.float32).reshape(-1)
         return (ld.expand(B) if ld.numel() == 1 else ld).contiguous()
     return torch.full((B,), float(logdet), dtype=torch.float32, device=device)
+
+
+class PreparedCond(dict):
+    """`rrdbResults` whose conditioning-only part of every coupling network is already in a workspace
+    (`FlowUpsamplerNet.prepare_cond`, `ifl_cond_prepare`).  Behaves as the plain dict everywhere; `FlowUpsamplerNet`
+    recognises it and skips that part while the workspace and the parameters are unchanged, and silently takes the
+    ordinary path otherwise.  Outputs are bit-identical either way."""
+
+    def __init__(self, rrdbResults, ws, generation, params_key, level_feats, shape):
+        super().__init__(rrdbResults)
+        self._ws, self._generation, self._params_key = ws, generation, params_key
+        self._level_feats, self._shape = level_feats, shape
+
+    def usable(self, ws, params_key, feats, shape):
+        return (ws is self._ws and ws.generation == self._generation and params_key == self._params_key
+                and shape == self._shape and set(feats) == set(self._level_feats)
+                and all(feats[lv] is self._level_feats[lv] for lv in feats))
 
 
 class FlowUpsamplerNet(nn.Module):
@@ -323,6 +341,33 @@ class FlowUpsamplerNet(nn.Module):
         return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot,
                            test_input_size=test_input_size)
 
+    def _load_cond(self, ws, feats, B, H, W):
+        L = hip.lib()
+        ws.generation += 1
+        for lv, ft in feats.items():
+            ft = hip._dev_f32(ft, f"rrdbResults level {lv}")
+            assert ft.shape == (B, N_RRDB_CH, H >> lv, W >> lv), (tuple(ft.shape), (B, N_RRDB_CH, H >> lv, W >> lv))
+            hip.check(L.ifl_load_cond(ws.ptr, B, H, W, lv, hip._ptr(ft), hip._stream()), "ifl_load_cond")
+
+    def prepare_cond(self, rrdbResults, batch, H, W, test_input_size=None):
+        """Compute, once, the part of every coupling network that depends only on the conditioning features (the first
+        3x3 conv over the 320 feature channels of fFeatures and fAffine; no counterpart call in the reference, which
+        recomputes it in each of the passes that `weighted_interpolate_image`, `generate_images.py` and `train.py` run
+        over one `lr_enc`).  Returns `rrdbResults` wrapped so that later encode/decode calls with the same batch and
+        image size reuse it.  H, W: size of the image the flow encodes (= the decode output)."""
+        enc = self._level_features(rrdbResults, H, test_input_size, decode=False)
+        dec = self._level_features(rrdbResults, H, test_input_size, decode=True)
+        if set(enc) != set(dec) or any(enc[lv] is not dec[lv] for lv in enc):
+            return rrdbResults                                    # encode and decode would pick different maps
+        dev = next(iter(enc.values())).device
+        params, layers = self._pack(dev)
+        ws = hip.Workspace.get(batch, H, W, dev)
+        with torch.cuda.device(dev):
+            self._load_cond(ws, enc, batch, H, W)
+            hip.check(hip.lib().ifl_cond_prepare(layers, len(layers), hip._ptr(params), ws.ptr, batch, H, W,
+                                                 hip._stream()), "ifl_cond_prepare")
+        return PreparedCond(rrdbResults, ws, ws.generation, self._packed[0], enc, (batch, H, W))
+
     def _run(self, src, rrdbResults, logdet, test_input_size, decode):
         src = hip._dev_f32(src, "flow input")
         B = src.shape[0]
@@ -341,15 +386,14 @@ class FlowUpsamplerNet(nn.Module):
         L = hip.lib()
         ld_in = _as_logdet(logdet, B, src.device)
         ld_out = torch.empty(B, dtype=torch.float32, device=src.device)
+        prepared = isinstance(rrdbResults, PreparedCond) and rrdbResults.usable(ws, self._packed[0], feats, (B, H, W))
         with torch.cuda.device(src.device):
-            for lv, ft in feats.items():
-                ft = hip._dev_f32(ft, f"rrdbResults level {lv}")
-                assert ft.shape == (B, N_RRDB_CH, H >> lv, W >> lv), (tuple(ft.shape), (B, N_RRDB_CH, H >> lv, W >> lv))
-                hip.check(L.ifl_load_cond(ws.ptr, B, H, W, lv, hip._ptr(ft), hip._stream()), "ifl_load_cond")
-            fn = L.ifl_flow_decode if decode else L.ifl_flow_encode
-            hip.check(fn(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
-                         hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps), hip._stream()),
-                      "ifl_flow_decode" if decode else "ifl_flow_encode")
+            if not prepared:
+                self._load_cond(ws, feats, B, H, W)
+            hip.check(L.ifl_flow_pass(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
+                                      hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps),
+                                      1 if decode else 0, hip.FLOW_COND_PREPARED if prepared else 0, hip._stream()),
+                      "ifl_flow_pass")
         return out, ld_out
 
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None, test_input_size=None):

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinterflow_hip.so")
 
 IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
+FLOW_COND_PREPARED = 1
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
@@ -58,6 +59,8 @@ def lib():
                  c_int, c_int, c_int, c_float, c_void_p]
     L.ifl_flow_encode.argtypes = flow_args
     L.ifl_flow_decode.argtypes = flow_args
+    L.ifl_cond_prepare.argtypes = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    L.ifl_flow_pass.argtypes = flow_args[:-1] + [c_int, c_int, c_void_p]
     L.ifl_flow_step.argtypes = [POINTER(IflLayer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
     sq = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -68,6 +71,8 @@ def lib():
     L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    L.ifl_quantize_u8_nhwc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_quantize_u8_nhwc.restype = c_int
     L.ifl_set_schedule.argtypes = [c_int, c_int, c_int]
     L.ifl_set_schedule.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
@@ -75,6 +80,7 @@ def lib():
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
     L.ifl_prof_read.restype = c_int
     for name in ("ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
+                 "ifl_cond_prepare", "ifl_flow_pass",
                  "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_gaussian_logp", "ifl_lerp"):
         getattr(L, name).restype = c_int
     _lib = L
@@ -84,7 +90,8 @@ def lib():
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
-           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule")
+           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_cond_prepare", "ifl_flow_pass",
+           "ifl_quantize_u8_nhwc")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
@@ -150,6 +157,7 @@ class Workspace:
             check(int(nbytes), "ifl_ws_bytes")
         self.B, self.H, self.W = B, H, W
         self.nbytes = nbytes
+        self.generation = 0          # bumped whenever the conditioning maps / slabs in this workspace are overwritten
         with torch.cuda.device(device):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.ifl_ws_init(_ptr(self.buf), nbytes, B, H, W, _stream()), "ifl_ws_init")
@@ -244,4 +252,14 @@ def lerp(za: torch.Tensor, zb: torch.Tensor, wa, wb) -> torch.Tensor:
     with torch.cuda.device(za.device):
         check(lib().ifl_lerp(_ptr(za), _ptr(zb), _ptr(wa_t), _ptr(wb_t), _ptr(out), B, za[0].numel(), _stream()),
               "ifl_lerp")
+    return out
+
+
+def quantize_u8_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """generate_images.py:89-91: `(np.clip(x, 0, 1) * 255).astype(np.uint8).transpose(0, 2, 3, 1)` on the GPU."""
+    x = _dev_f32(x, "quantize_u8_nhwc input")
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().ifl_quantize_u8_nhwc(_ptr(x), _ptr(out), B, C, H, W, _stream()), "ifl_quantize_u8_nhwc")
     return out

@@ -237,3 +237,92 @@ def test_lerp():
     z1, z2 = torch.randn(2, 3, 5, 7, generator=gen), torch.randn(2, 3, 5, 7, generator=gen)   # n % 4 != 0
     assert torch.equal(hip.lerp(z1.to(dev()), z2.to(dev()), w[:2], 1 - w[:2]).cpu(),
                        w[:2].reshape(-1, 1, 1, 1) * z1 + (1 - w[:2]).reshape(-1, 1, 1, 1) * z2)
+
+
+# ----------------------------------------------------------------------------- conditioning reuse, generation loop
+def test_prepared_cond_is_bit_identical(model):
+    """ifl_cond_prepare + ifl_flow_pass(IFL_FLOW_COND_PREPARED) run the same kernels in the same order as the plain
+    passes: outputs must match bit for bit, for several passes over one preparation, and a workspace that was reused
+    for other features in between must be detected (ordinary path, same results)."""
+    from interflow_amd.flow_modules import PreparedCond
+    B, H, W = 3, 32, 48
+    fu = model.flow_upsampler
+    x1, x2 = (t(synth.synth_images(s, B, H, W)).to(dev()) for s in (41, 42))
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(43, B, H, W).items()}
+    other = {k: t(v).to(dev()) for k, v in synth.synth_features(44, B, H, W).items()}
+    ld0 = torch.zeros(B, device=dev())
+    z1, l1 = fu(gt=x1, rrdbResults=feats, logdet=ld0, reverse=False)
+    z2, l2 = fu(gt=x2, rrdbResults=feats, logdet=ld0, reverse=False)
+    xr, lr = fu(z=z1, rrdbResults=feats, logdet=ld0, reverse=True)
+    prep = fu.prepare_cond(feats, B, H, W)
+    assert isinstance(prep, PreparedCond) and set(prep) == set(feats)
+    gen = prep._ws.generation
+    for _ in range(2):
+        a, b = fu(gt=x1, rrdbResults=prep, logdet=ld0, reverse=False)
+        assert torch.equal(a, z1) and torch.equal(b, l1)
+        a, b = fu(gt=x2, rrdbResults=prep, logdet=ld0, reverse=False)
+        assert torch.equal(a, z2) and torch.equal(b, l2)
+        a, b = fu(z=z1, rrdbResults=prep, logdet=ld0, reverse=True)
+        assert torch.equal(a, xr) and torch.equal(b, lr)
+    assert prep._ws.generation == gen, "prepared passes must not reload the conditioning"
+    zo, _ = fu(gt=x1, rrdbResults=other, logdet=ld0, reverse=False)          # overwrites the workspace's slabs
+    assert not torch.equal(zo, z1) and prep._ws.generation != gen
+    a, b = fu(gt=x1, rrdbResults=prep, logdet=ld0, reverse=False)            # stale preparation: ordinary path
+    assert torch.equal(a, z1) and torch.equal(b, l1)
+    # a parameter update invalidates it too
+    prep = fu.prepare_cond(feats, B, H, W)
+    with torch.no_grad():
+        fu.layers[3].actnorm.bias.add_(0.0)                                   # bumps the version counter only
+    a, b = fu(gt=x1, rrdbResults=prep, logdet=ld0, reverse=False)
+    assert torch.equal(a, z1) and torch.equal(b, l1)
+
+
+def test_quantize_u8_bit_exact():
+    g = torch.Generator().manual_seed(9)
+    for shape in ((2, 3, 160, 160), (1, 3, 5, 7), (3, 1, 4, 4), (2, 4, 6, 10), (0, 3, 4, 4)):
+        x = torch.rand(*shape, generator=g) * 1.4 - 0.2
+        if x.numel():
+            x.view(-1)[:6] = torch.tensor([0.0, 1.0, -0.0, 254.5 / 255, 1.0 / 255, 0.999999])
+        want = (np.clip(x.numpy(), 0., 1.0) * 255).astype(np.uint8).transpose(0, 2, 3, 1)      # generate_images.py:89-91
+        got = hip.quantize_u8_nhwc(x.to(dev())).cpu().numpy()
+        assert got.dtype == np.uint8 and np.array_equal(got, want), shape
+    with pytest.raises(NotImplementedError):
+        hip.quantize_u8_nhwc(torch.zeros(1, 2, 4, 4, device=dev()))
+
+
+def test_generate_tiles_and_sharding(sd, model):
+    """BASELINE.json configs[2] in small: tiled latent-interpolation generation.  Every tile equals the oracle's
+    weighted_interpolate of that tile; the union of two ranks' units equals the single-rank result bit for bit."""
+    from interflow_amd import generate, shard
+    N, H, W, T = 2, 32, 48, 32
+    gt, la, lb = (t(synth.synth_images(s, N, H, W)) for s in (51, 52, 53))
+    weights = [0.25, 0.7]
+    gd, lad, lbd = gt.to(dev()), la.to(dev()), lb.to(dev())
+    units, res = generate.generate(model, gd, lad, lbd, weights, tile=T, batch=3)
+    assert len(units) == N * 2 and units[1] == (0, 0, 32, 32, 16)
+    full = generate.assemble(units, res, N, H, W, len(weights), dev())
+    for (n, y, x, h, w), r in zip(units, res):
+        crop = lambda a: a[n:n + 1, :, y:y + h, x:x + w]
+        lr_enc = O.rrdb_preprocessing(crop(gt), sd, "arch.RRDB.")
+        for wi, a in enumerate(weights):
+            want = O.weighted_interpolate(sd, crop(la), crop(lb), a, lr_enc)
+            want_u8 = (np.clip(want.numpy(), 0., 1.0) * 255).astype(np.uint8).transpose(0, 2, 3, 1)[0]
+            diff = np.abs(r[wi].cpu().numpy().astype(np.int32) - want_u8.astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).mean() < 0.01, (n, y, x, wi, diff.max(), (diff != 0).mean())
+    # float outputs against the oracle at the parity tolerance
+    outs = generate.interpolate_batch(model, gd[:, :, :, :32], lad[:, :, :, :32], lbd[:, :, :, :32], weights, quantize=False)
+    lr_enc = O.rrdb_preprocessing(gt[:, :, :, :32], sd, "arch.RRDB.")
+    for wi, a in enumerate(weights):
+        rel_close(outs[wi], O.weighted_interpolate(sd, la[:, :, :, :32], lb[:, :, :, :32], a, lr_enc), 2e-4, what=f"w={a}")
+    # two ranks
+    merged = torch.zeros_like(full)
+    seen = []
+    for r in range(2):
+        u, rs = generate.generate(model, gd, lad, lbd, weights, tile=T, batch=3, rank=r, world=2)
+        seen += u
+        merged += generate.assemble(u, rs, N, H, W, len(weights), dev())
+    assert seen == units and torch.equal(merged, full)
+    # whole-image mode (tile=None) is what the reference does
+    u, rs = generate.generate(model, gd, lad, lbd, weights[:1], tile=None)
+    want = model.weighted_interpolate_image(lad, lbd, weights[0], cond_gt=gd)
+    assert torch.equal(rs[0][0], hip.quantize_u8_nhwc(want)[0])
