@@ -321,7 +321,10 @@ def test_generate_tiles_and_sharding(sd, model):
         u, rs = generate.generate(model, gd, lad, lbd, weights, tile=T, batch=3, rank=r, world=2)
         seen += u
         merged += generate.assemble(u, rs, N, H, W, len(weights), dev())
-    assert seen == units and torch.equal(merged, full)
+    # the flow kernels are batch-invariant (test_batch32_properties); the RRDB encoder still runs on PyTorch-ROCm, whose
+    # conv algorithm may change with the batch size, so ranks that batch differently may differ in the last float bit
+    d = (merged.int() - full.int()).abs()
+    assert seen == units and int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.01
     # whole-image mode (tile=None) is what the reference does
     u, rs = generate.generate(model, gd, lad, lbd, weights[:1], tile=None)
     want = model.weighted_interpolate_image(lad, lbd, weights[0], cond_gt=gd)
