@@ -43,9 +43,9 @@ def main():
     N, S = args.images, args.size
     gt, la, lb = (torch.rand(N, 3, S, S, device=dev, generator=g) for _ in range(3))
     weights = generate.default_weights(0)
-    # warm-up on one batch of tiles
-    generate.generate(model, gt[:1, :, :args.tile, :args.tile * 2], la[:1, :, :args.tile, :args.tile * 2],
-                      lb[:1, :, :args.tile, :args.tile * 2], weights[:2], tile=args.tile, batch=args.batch)
+    # warm-up: the same job with two weights, so that every (batch, tile shape) the timed run uses has been seen
+    # (MIOpen picks its conv algorithms for the PyTorch-ROCm RRDB encoder on first use: seconds per new shape)
+    generate.generate(model, gt, la, lb, weights[:2], tile=args.tile, batch=args.batch, rank=rank, world=world)
     shard.barrier(dist, dev)
     t0 = time.perf_counter()
     units, res = generate.generate(model, gt, la, lb, weights, tile=args.tile, batch=args.batch, rank=rank, world=world)
