@@ -263,7 +263,7 @@ static int check_layers(const ifl_layer* layers, int n_layers)
 // own stream, forked from and joined back to the caller's stream with events.
 // The auxiliary streams and events are created once per device on first use and kept for the life of the process.
 #define IFL_MAX_GROUPS 4
-#define IFL_P1_CHUNK 4
+#define IFL_P1_CHUNK 8
 namespace {
 constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
 struct ForkCtx {
@@ -303,10 +303,11 @@ int env_int(const char* name, int dflt)
 }
 
 // schedule knobs: defaults, overridable by the environment (read once) and by ifl_set_schedule()
-struct Sched { int aux, groups, chunk; };
+struct Sched { int aux, groups, chunk, chunk2; };      // chunk: level-1 steps per bulk launch, chunk2: deeper levels
 Sched& sched()
 {
-    static Sched s{env_int("IFL_AUX_STREAM", 1), env_int("IFL_GROUPS", 2), env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK)};
+    static Sched s{env_int("IFL_AUX_STREAM", 1), env_int("IFL_GROUPS", 2), env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK),
+                   env_int("IFL_P1_CHUNK_STEPS_L2", IFL_P1_CHUNK)};
     return s;
 }
 
@@ -356,7 +357,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
 {
     const IflLevelWs& lv = w.lv[lvl];
     const int n = plan.n[lvl];
-    const int chunk = chunk_override > 0 ? chunk_override : sched().chunk;
+    const int chunk = chunk_override > 0 ? chunk_override : (lvl == 0 ? sched().chunk : sched().chunk2);
     IflStepOff off = ifl_step_off(lv.C, 1);
     const int nchunks = ifl_cdiv(n, chunk);
     for (int c = 0; c < nchunks; ++c) {
@@ -378,13 +379,13 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
                 hipStream_t st, hipEvent_t* ev)
 {
     const int B = w.B, H = w.H, W = w.W;
-    const int chunk = sched().chunk;
+    const int chunk_of[2] = {sched().chunk, sched().chunk2};
     int rc = 0, slots = 0;
     double constant = 0.0;
     int waited[IFL_MAX_LEVELS][IFL_MAX_COND] = {};
     auto wait_slab = [&](int lvl, int slab) -> int {
         if (!ev) return 0;
-        const int ci = slab / chunk;
+        const int ci = slab / chunk_of[lvl == 0 ? 0 : 1];
         if (!waited[lvl][ci]) { IFL_HIP(hipStreamWaitEvent(st, ev[lvl * IFL_MAX_COND + ci], 0)); waited[lvl][ci] = 1; }
         return 0;
     };
@@ -484,7 +485,7 @@ extern "C" int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps)
     Sched& s = sched();
     if (aux_stream >= 0) s.aux = aux_stream != 0;
     if (groups >= 1) s.groups = groups;
-    if (p1_chunk_steps >= 1) s.chunk = p1_chunk_steps;
+    if (p1_chunk_steps >= 1) s.chunk = s.chunk2 = p1_chunk_steps;
     return 0;
 }
 

@@ -130,11 +130,16 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
     constexpr int NT = 2;
     __shared__ __attribute__((aligned(16))) float lds[LD_SLOTS * 32 * IFL_CS];   // >= IFL_PP_MAX pixels: staging stores need no bound test
 
-    const IflTile t = ifl_tile(g, blockIdx.x);
+    // Workgroup -> (tile, image, step) = (x, y, z), step slowest: at any moment the chip works on one or two steps, whose
+    // weights (1.5 MB per step, streamed by every workgroup) stay in the XCDs' L2s.  Grouping the steps of one tile on
+    // one XCD instead (so that they share the conditioning patch in L2) was measured 10 % slower: four steps' weights
+    // no longer fit beside the patches (profiles/r01_ab_schedule.txt).
+    const int tile = blockIdx.x, step = blockIdx.z;
+    const IflTile t = ifl_tile(g, tile);
     if (!t.active) return;                    // uniform for the whole workgroup
     const int b = blockIdx.y;
-    const float* prm = params + steps.off[blockIdx.z];
-    float* h2P = h2all + (int64_t)blockIdx.z * h2_step_stride;
+    const float* prm = params + steps.off[step];
+    float* h2P = h2all + (int64_t)step * h2_step_stride;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
