@@ -153,6 +153,35 @@ void quantize_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, 
     }
 }
 
+// factor-2 fast path (the only factor the model uses), W % 8 == 0: one thread per 4 consecutive squeezed pixels of one
+// input channel -- two rows of 8 input floats (float4 x 4) <-> four channel planes x float4, every access 16 bytes.
+__global__ __launch_bounds__(256)
+void squeeze2_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t nthreads, int C, int H, int W, int reverse)
+{
+    const int Ho = H / 2, Wo = W / 2, Wq = Wo / 4;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nthreads) return;
+    int wq = e % Wq; int64_t t = e / Wq; int h = t % Ho; t /= Ho; int c = t % C; int b = t / C;
+    const int64_t l0 = (((int64_t)b * C + c) * H + 2 * h) * W + 8 * wq;                   // large tensor, row 2h
+    const int64_t s0 = (((int64_t)b * C * 4 + 4 * c) * Ho + h) * Wo + 4 * wq;             // squeezed tensor, channel 4c
+    const int64_t plane = (int64_t)Ho * Wo;
+    if (!reverse) {
+        f32x4 r0a = *(const f32x4*)(in + l0), r0b = *(const f32x4*)(in + l0 + 4);
+        f32x4 r1a = *(const f32x4*)(in + l0 + W), r1b = *(const f32x4*)(in + l0 + W + 4);
+        *(f32x4*)(out + s0) = f32x4{r0a[0], r0a[2], r0b[0], r0b[2]};                      // (i, j) = (0, 0)
+        *(f32x4*)(out + s0 + plane) = f32x4{r0a[1], r0a[3], r0b[1], r0b[3]};              // (0, 1)
+        *(f32x4*)(out + s0 + 2 * plane) = f32x4{r1a[0], r1a[2], r1b[0], r1b[2]};          // (1, 0)
+        *(f32x4*)(out + s0 + 3 * plane) = f32x4{r1a[1], r1a[3], r1b[1], r1b[3]};          // (1, 1)
+    } else {      // in = squeezed, out = large
+        f32x4 a = *(const f32x4*)(in + s0), bq = *(const f32x4*)(in + s0 + plane);
+        f32x4 cq = *(const f32x4*)(in + s0 + 2 * plane), d = *(const f32x4*)(in + s0 + 3 * plane);
+        *(f32x4*)(out + l0) = f32x4{a[0], bq[0], a[1], bq[1]};
+        *(f32x4*)(out + l0 + 4) = f32x4{a[2], bq[2], a[3], bq[3]};
+        *(f32x4*)(out + l0 + W) = f32x4{cq[0], d[0], cq[1], d[1]};
+        *(f32x4*)(out + l0 + W + 4) = f32x4{cq[2], d[2], cq[3], d[3]};
+    }
+}
+
 }  // namespace
 
 int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st)
@@ -223,6 +252,12 @@ int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, 
 {
     int64_t n = (int64_t)B * C * H * W;
     if (n == 0) return 0;
+    if (f == 2 && W % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        int64_t nt = n / 16;
+        hipLaunchKernelGGL(squeeze2_vec_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, in, out, nt, C, H, W, reverse);
+        IFL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(squeeze_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, C, H, W, f, reverse);
     IFL_LAUNCH_CHECK();
     return 0;

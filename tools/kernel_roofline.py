@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""Per-kernel roofline table (BASELINE.json north_star: "rocprof roofline fractions reported for every kernel").
+
+Times every kernel of the path alone on one stream with HIP events, at the benchmark's size (batch 32 of 160x160
+patches) and, for the bandwidth-bound kernels, at a size past the 256 MiB Infinity Cache, and prices it against its
+bound: algorithmic bytes / duration vs 8 TB/s HBM, or algorithmic FLOP / duration vs 157.3 TFLOP/s fp32 MFMA
+(MI355X_MICROARCH.md).  Algorithmic = what the reference's operator must move or compute, not what the kernel executes.
+
+  python tools/kernel_roofline.py [--out gpurun_out/kernel_roofline.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from interflow_amd import hip, synth  # noqa: E402
+from interflow_amd.flow_model import InterpFlow  # noqa: E402
+
+HBM, MFMA = 8000.0, 157.3      # GB/s, TFLOP/s
+
+
+def ev_time(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3          # seconds per call
+
+
+def lib_time(kid, fn, reps=5, warm=2):
+    """Mean duration of the launches of library kernel id `kid` inside fn() (event pairs inside the library)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    hip.prof_enable([kid])
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ms, n = hip.prof_read(kid)
+    hip.prof_enable([])
+    return ms * 1e-3 / max(n, 1), n // reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "kernel_roofline.json"))
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    hip.set_schedule(aux_stream=0, groups=1)                 # kernels strictly one after another
+    model = InterpFlow([2, 4])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_interpflow_state([2, 4], seed=0).items()})
+    model.eval().to(dev)
+    fu = model.flow_upsampler
+    rows = []
+
+    def add(kernel, what, bound, work, secs, size):
+        if bound == "hbm":
+            ach, peak, unit = work / secs / 1e9, HBM, "GB/s"
+        else:
+            ach, peak, unit = work / secs / 1e12, MFMA, "TFLOP/s"
+        rows.append({"kernel": kernel, "replaces": what, "bound": bound, "size": size, "us": secs * 1e6,
+                     "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+
+    g = torch.Generator(device=dev).manual_seed(3)
+    with torch.inference_mode():
+        for B in (32, 1024):
+            size = f"B={B} 160x160"
+            x = torch.rand(B, 3, 160, 160, device=dev, generator=g)
+            n = x.numel()
+            s = ev_time(lambda: hip.squeeze2d(x))
+            add("squeeze2_vec_kernel", "squeeze2d flow.py:163-176", "hbm", 2 * 4 * n, s, size)
+            y = hip.squeeze2d(x)
+            s = ev_time(lambda: hip.unsqueeze2d(y))
+            add("squeeze2_vec_kernel (reverse)", "unsqueeze2d flow.py:179-193", "hbm", 2 * 4 * n, s, size)
+            s = ev_time(lambda: hip.quantize_u8_nhwc(x))
+            add("quantize_u8_kernel", "clip*255->uint8 NHWC generate_images.py:89-91", "hbm", 5 * n, s, size)
+            z = torch.randn(B, 48, 40, 40, device=dev, generator=g)
+            z2 = torch.randn(B, 48, 40, 40, device=dev, generator=g)
+            s = ev_time(lambda: hip.lerp(z, z2, 0.3, 0.7))
+            add("lerp_kernel", "latent interpolation flow_model.py:198", "hbm", 3 * 4 * z.numel(), s, size)
+            s = ev_time(lambda: hip.gaussian_logp(z))
+            add("logp_kernel (standard normal)", "Gaussian.logp flow.py:158-161", "hbm", 4 * z.numel(), s, size)
+            cov = model.cov_shift_1 @ model.cov_shift_1.T
+            ci, mu = torch.inverse(cov).contiguous(), (model.mean_shift_1 * torch.ones(48, device=dev)).contiguous()
+            s = ev_time(lambda: hip.gaussian_logp(z, mu, ci, 0.0))
+            add("logp_kernel<48> (full covariance)", "Gaussian.logp flow.py:146-157", "hbm", 4 * z.numel(), s, size)
+            if B > 256:
+                continue
+            # one FlowStep without coupling: the fused ActNorm + 1x1 conv kernel, timed inside the library
+            for li, C, hw in ((1, 12, 80), (20, 48, 40)):
+                step = fu.layers[li]
+                zz = torch.randn(B, C, hw, hw, device=dev, generator=g)
+                s, _ = lib_time(hip.K_ANIC, lambda: step(zz, None, reverse=False))
+                add(f"anic_kernel<{C}>", "ActNorm2d + InvertibleConv1x1 FlowActNorms.py:87-92, Permutations.py:114-118",
+                    "hbm", 2 * 4 * zz.numel(), s, f"B={B} {C}x{hw}x{hw}")
+        # the coupling-network kernels inside a whole encode / decode at the benchmark size
+        B = 32
+        x = torch.rand(B, 3, 160, 160, device=dev, generator=g)
+        feats = {k: (torch.rand(B, 320, 160 // d, 160 // d, device=dev, generator=g) * 2 - 1) * float(np.sqrt(3.0))
+                 for k, d in (("fea_up4", 1), ("fea_up2", 2), ("fea_up1", 4))}
+        z, _ = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        enc = lambda: model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        dec = lambda: model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        both = lambda: (enc(), dec())
+        px = {1: 6400, 2: 1600}
+        size = "B=32 160x160, one pass"
+        for kid, lvl, name in ((hip.K_CONV1_FT_L1, 1, "conv1_ft_kernel<1>"), (hip.K_CONV1_FT_L2, 2, "conv1_ft_kernel<2>")):
+            s, n = lib_time(kid, enc)
+            flop = 2.0 * (2 * 64 * 9 * 320 + 64 * 64) * px[lvl] * B * 16 / n
+            add(name, "first 3x3 conv of fFeatures+fAffine over ft, fFeatures 1x1 (flow.py:25-64)", "mfma", flop, s,
+                f"B=32, level {lvl}, {16 // n} steps per launch")
+        s, n = lib_time(hip.K_CONV1_FINISH, enc)
+        flop = 2.0 * sum((64 * 9 * (C // 2) + 64 * 64) * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
+        add("conv1_finish_kernel", "fAffine z1 taps + ActNorm/ReLU/1x1 (Ablation.py:228-233)", "mfma", flop, s,
+            "B=32, mean of the two levels")
+        for kid, fn, name in ((hip.K_CONV3_ENC, enc, "conv3_kernel<*,*,0> (encode)"),
+                              (hip.K_CONV3_DEC, dec, "conv3_kernel<*,*,1|2> (decode, two launches per step)")):
+            s, n = lib_time(kid, fn)
+            flop = 2.0 * sum(64 * 9 * 3 * C * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
+            add(name, "Conv2dZeros 3x3 + sigmoid + affine coupling + sum log scale (flow.py:67-82, Ablation.py:167-240)",
+                "mfma", flop, s, "B=32, mean of the two levels")
+        s = ev_time(both, reps=5, warm=2)
+        add("whole path (encode + decode), one stream", "InterpFlow.forward both directions", "mfma", 213.1e9 * B, s, "B=32")
+    hip.set_schedule(aux_stream=1, groups=2)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(rows, open(args.out, "w"), indent=1)
+    md = ["| kernel | replaces | size | µs | achieved | peak | frac | bound |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        md.append("| `%s` | %s | %s | %.1f | %.1f %s | %.1f | %.3f | %s |" % (
+            r["kernel"], r["replaces"], r["size"], r["us"], r["achieved"], r["unit"], r["peak"], r["frac"], r["bound"]))
+    open(os.path.splitext(args.out)[0] + ".md", "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
