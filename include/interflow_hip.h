@@ -148,6 +148,24 @@ int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, f
 int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,
              int B, int64_t n_per_sample, void* stream);
 
+/* ---- conditioning encoder ----
+ * RRDBNet.forward(get_steps=True) (RRDBNet_arch.py:85-148) followed by RRDBGlowNet.rrdbPreprocessing
+ * (RRDBGlowNet_arch.py:217-246) for the shipped options (scale 4, nf 64, gc 32, stackRRDB concat): x [B,3,H,W] ->
+ *   fea_up1 [B,64*(1+n_blocks),H/4,W/4]  (= 'last_lr_fea'),  fea_up2 [..,H/2,W/2],  fea_up4 [..,H,W],  fea_up0 [..,H/8,W/8],
+ *   out [B,3,H,W],  blocks_out [n_blocks][B,64,H/4,W/4]  ('block_k' for k in block_idxs)
+ * all contiguous NCHW float32; an output pointer may be NULL, and the layers only it needs are skipped.
+ * params: ifl_rrdb_param_floats(nb) floats, one record per convolution in execution order (conv_first, RRDB_trunk.k.RDBr.convc,
+ * trunk_conv, upconv1, upconv2, HRconv, conv_last); ifl_rrdb_conv_desc gives each record's padded channel counts and the
+ * float offsets of its weights (fragment order) and bias.  ws: ifl_rrdb_ws_bytes bytes, ifl_rrdb_ws_init once. */
+int     ifl_rrdb_conv_count(int nb);
+int64_t ifl_rrdb_param_floats(int nb);
+int     ifl_rrdb_conv_desc(int nb, int idx, int* cin, int* cout, int64_t* w_off, int64_t* b_off);
+int64_t ifl_rrdb_ws_bytes(int B, int H, int W, int n_blocks);
+int     ifl_rrdb_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, int n_blocks, void* stream);
+int     ifl_rrdb_encode(const float* params, int nb, const int* block_idxs, int n_blocks, void* ws, const float* x,
+                        float* fea_up1, float* fea_up2, float* fea_up4, float* fea_up0, float* out, float* blocks_out,
+                        int B, int H, int W, void* stream);
+
 /* Image quantisation of the generation loop, generate_images.py:89-91:
  * out[b,h,w,c] = (uint8)(clip(x[b,c,h,w], 0, 1) * 255)   (NCHW float32 -> NHWC uint8, bit-exact with numpy).  C in {1,3,4}. */
 int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);

@@ -91,7 +91,7 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
 
 // ---- tiling ---------------------------------------------------------------------------------------------------
 // Pick the band width that minimises (MFMA lane slots, then staged patch pixels) subject to the LDS patch bound.
-static IflGeom choose_geom(int H, int W)
+IflGeom ifl_choose_geom(int H, int W)
 {
     IflGeom best{};
     double best_cost = -1;
@@ -133,7 +133,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
         lv.ha = take(ring * IFL_HID);
-        lv.geom = choose_geom(lv.H, lv.W);
+        lv.geom = ifl_choose_geom(lv.H, lv.W);
         slots += 2 * 16 * lv.geom.ntiles;
     }
     w.ld_slots = ifl_roundup(slots, 64);

@@ -1,0 +1,164 @@
+// convg.hip -- generic 3x3 / 1x1 'same' convolution on ringed channels-last planes as an implicit GEMM on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32), with a fused epilogue: bias, (leaky) ReLU, up to two scaled residual adds.
+//
+// Used by the conditioning encoder (rrdb.hip): every nn.Conv2d of RRDBNet (RRDBNet_arch.py:13-17,60-75) including the
+// dense concatenations of ResidualDenseBlock_5C (torch.cat at :25-28 becomes "read the first Cin channels of the
+// block's buffer, write 32 more behind them") and its residuals (x5*0.2 + x, :29; out*0.2 + x, :45).
+//
+// GEMM orientation and fragments are those of conv1.hip: D[out ch][pixel] += W[out ch][k] * X[k][pixel], k = (tap, in
+// channel); weights pre-packed in fragment order and streamed global -> VGPR, the (rows+2) x (bw+2) pixel patch of a
+// 32-channel chunk staged in LDS and reused by the taps and the four waves.  One workgroup = 128 pixels x (32*MT) output
+// channels; wave w owns pixels [32w, 32w+32).
+#include "ifl_common.h"
+
+namespace {
+
+constexpr int LD_SLOTS = (IFL_PP_MAX * 8 + 255) / 256;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+template <int MT, int TAPS>
+__global__ __launch_bounds__(256, 2)
+void convg_kernel(IflConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[LD_SLOTS * 32 * IFL_CS];
+    const IflGeom& g = a.g;
+    const IflTile t = ifl_tile(g, blockIdx.x);
+    if (!t.active) return;
+    const int b = blockIdx.y, grp = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int W2 = g.W + 2;
+    const int64_t plane = (int64_t)(g.H + 2) * W2;
+
+    // this lane's pixel
+    int a0;
+    int64_t opix;
+    {
+        int idx = t.s + wave * 32 + j;
+        bool valid = idx < t.npx;
+        int idc = valid ? idx : t.npx - 1;
+        int ty = idc / t.bwb, tx = idc - ty * t.bwb;
+        constexpr int HALO = TAPS == 9 ? 1 : 0;                   // 1x1: the patch still has the halo, read its centre
+        a0 = (((ty - t.y_first - 1 + (1 - HALO)) * t.PW + tx + (1 - HALO)) * IFL_CS + 4 * h) * 4;
+        opix = valid ? ((int64_t)b * plane + (int64_t)(ty + 1) * W2 + t.x0 + tx + 1) : -1;
+    }
+
+    int srcpix[LD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LD_SLOTS; ++i) {
+        int p = (tid + i * 256) >> 3;
+        int r = p / t.PW, c = p - r * t.PW;
+        srcpix[i] = (p < t.PP) ? ((t.y_first + 1 + r) * W2 + t.x0 + c) : 0;
+    }
+    const int q4 = (tid & 7) * 4;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int nchunks = a.nchunks;
+    constexpr int KQ = 4;                                         // k-steps of 8 channels per 32-channel chunk
+    const float* wl = a.w + (int64_t)grp * nchunks * (TAPS * KQ * MT * 256) + lane * 4;
+
+    auto chunk_src = [&](int cc, int i) -> const float* {         // source pointer of staging slot i for chunk cc
+        int s = 0, c = cc;
+        if (a.nsrc > 1 && cc >= a.src_chunks[0]) { s = 1; c = cc - a.src_chunks[0]; }
+        return a.src[s] + ((int64_t)b * plane + srcpix[i]) * a.src_stride[s] + a.src_off[s] + c * IFL_CK + q4;
+    };
+
+    f32x4 stage[LD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(0, i);
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LD_SLOTS; ++i) {
+            int idx = tid + i * 256;
+            *(f32x4*)&lds[(idx >> 3) * IFL_CS + (idx & 7) * 4] = stage[i];
+        }
+        __syncthreads();
+        if (cc + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(cc + 1, i);
+        }
+        const float* wc = wl + (int64_t)cc * (TAPS * KQ * MT * 256);
+        constexpr int ITERS = TAPS * KQ;
+        f32x4 wq[2][MT], xb[2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wq[0][m] = *(const f32x4*)(wc + m * 256);
+        xb[0] = *(const f32x4*)((const char*)lds + a0);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it + 1 < ITERS) {
+                const int tap = (it + 1) / KQ, kq = (it + 1) % KQ;
+                const int tapoff = TAPS == 9 ? ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4) : 0;
+                xb[(it + 1) & 1] = *(const f32x4*)((const char*)lds + a0 + tapoff + kq * 32);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + ((it + 1) * MT + m) * 256);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma32(wq[it & 1][m][e], xb[it & 1][e], acc[m]);
+        }
+    }
+
+    if (opix < 0) return;
+    // epilogue: accumulator element (m, r) of lane (j, h) is output channel m*32 + (r&3) + 8*(r>>2) + 4*h of pixel j
+    const int cbase = grp * 32 * MT + 4 * h;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c = cbase + m * 32 + gq * 8;
+            f32x4 v = {acc[m][gq * 4], acc[m][gq * 4 + 1], acc[m][gq * 4 + 2], acc[m][gq * 4 + 3]};
+            if (a.bias) {
+                f32x4 bb = *(const f32x4*)(a.bias + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + bb[e];
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.2f;
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            if (a.res1) {
+                f32x4 r = *(const f32x4*)(a.res1 + opix * a.res1_stride + a.res1_off + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v[e] * a.alpha; v[e] = v[e] + r[e]; }
+            }
+            if (a.res2) {
+                f32x4 r = *(const f32x4*)(a.res2 + opix * a.res2_stride + a.res2_off + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v[e] * a.beta; v[e] = v[e] + r[e]; }
+            }
+            *(f32x4*)(a.out + opix * a.out_stride + a.out_off + c) = v;
+        }
+}
+
+}  // namespace
+
+int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
+{
+    IFL_CHECK_ARG(a.cout % 32 == 0 && a.cout > 0, IFL_EINVAL, "convg: Cout=%d is not a multiple of 32", a.cout);
+    IFL_CHECK_ARG(a.taps == 9 || a.taps == 1, IFL_EINVAL, "convg: taps=%d", a.taps);
+    IFL_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2 && a.nchunks >= 1, IFL_EINVAL, "convg: sources");
+    const int mt = (a.cout % 64 == 0) ? 2 : 1;
+    dim3 grid(a.g.ntiles, B, a.cout / (32 * mt)), block(256);
+    if (mt == 2 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<2, 9>), grid, block, 0, st, a);
+    else if (mt == 1 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9>), grid, block, 0, st, a);
+    else if (mt == 2) hipLaunchKernelGGL((convg_kernel<2, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((convg_kernel<1, 1>), grid, block, 0, st, a);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

@@ -114,6 +114,23 @@ struct IflWs {
     int64_t bytes;
 };
 
+// ---- generic convolution (convg.hip) ------------------------------------------------------------------------------
+// Input channels = up to two sources read one after the other (each a channel range, a multiple of 32 wide, of a ringed
+// channels-last buffer); output = `cout` channels (multiple of 32) written at channel out_off of a ringed buffer.
+//   v = conv + bias;  act (1 LeakyReLU 0.2, 2 ReLU);  if res1: v = v*alpha + res1;  if res2: v = v*beta + res2.
+// Weights: [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][lane half h][lane i][e] =
+//          W[out = group*32*MT + mt*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap]   (MT = 2 when cout % 64 == 0, else 1).
+struct IflConvArgs {
+    const float* src[2]; int src_stride[2], src_off[2], src_chunks[2]; int nsrc, nchunks;
+    const float* w; const float* bias;
+    float* out; int out_stride, out_off; int cout, taps, act;
+    const float* res1; int res1_stride, res1_off; float alpha;
+    const float* res2; int res2_stride, res2_off; float beta;
+    IflGeom g;
+};
+int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
+IflGeom ifl_choose_geom(int H, int W);
+
 int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out);     // base may be NULL (size query)
 void ifl_set_error(const char* fmt, ...);
 

@@ -137,7 +137,72 @@ class RRDBGlowNet(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("RRDBGlowNet.forward (DeFlow legacy) is not used by InterFlow; call InterpFlow")
 
+    def _needs_autograd(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.RRDB.parameters())
+
+    def _rrdb_hip(self, lr):
+        """RRDBNet.forward(get_steps=True) + the stacking below, through ifl_rrdb_encode (inference only)."""
+        import ctypes
+        from . import pack
+        lr = hip._dev_f32(lr, "rrdbPreprocessing input")
+        B, C, H, W = lr.shape
+        assert C == 3, C
+        assert H % 4 == 0 and W % 4 == 0, "{}".format((H, W, 4))           # F.unfold(..., 4).view(...) would fail
+        block_idxs = list(opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or [])
+        nb = len(self.RRDB.RRDB_trunk)
+        key = (tuple((p.data_ptr(), p._version) for p in self.RRDB.parameters()), str(lr.device))
+        if getattr(self, "_rrdb_packed", None) is None or self._rrdb_packed[0] != key:
+            prm = {k: v.detach().to("cpu", torch.float32).numpy() for k, v in self.RRDB.state_dict().items()}
+            self._rrdb_packed = (key, torch.from_numpy(pack.pack_rrdb(prm, nb)).to(lr.device))
+        params = self._rrdb_packed[1]
+        L = hip.lib()
+        wkey = (B, H, W, len(block_idxs), lr.device.index, torch.cuda.current_stream().cuda_stream)
+        cache = self.__dict__.setdefault("_rrdb_ws", {})
+        if wkey not in cache:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            n = L.ifl_rrdb_ws_bytes(B, H, W, len(block_idxs))
+            if n < 0:
+                hip.check(int(n), "ifl_rrdb_ws_bytes")
+            buf = torch.empty(n, dtype=torch.uint8, device=lr.device)
+            with torch.cuda.device(lr.device):
+                hip.check(L.ifl_rrdb_ws_init(hip._ptr(buf), n, B, H, W, len(block_idxs), hip._stream()), "ifl_rrdb_ws_init")
+            cache[wkey] = buf
+        ws = cache[wkey]
+        Ct = 64 * (1 + len(block_idxs))
+
+        def new(c, h, w):
+            return torch.empty(B, c, h, w, dtype=torch.float32, device=lr.device)
+        up1, up2, up4 = new(Ct, H // 4, W // 4), new(Ct, H // 2, W // 2), new(Ct, H, W)
+        up0 = None
+        if opt_get(self.opt, ['network_G', 'flow', 'fea_up0']) or False:
+            if H // 8 == 0 or W // 8 == 0:                  # F.interpolate(scale_factor=1/2) of RRDBNet_arch.py:138 raises
+                raise RuntimeError(f"Input and output sizes should be greater than 0, but got input (H: {H // 4}, "
+                                   f"W: {W // 4}) output (H: {H // 8}, W: {W // 8})")
+            up0 = new(Ct, H // 8, W // 8)
+        out = new(3, H, W)
+        blocks = torch.empty(len(block_idxs), B, 64, H // 4, W // 4, dtype=torch.float32, device=lr.device)
+        idx = (ctypes.c_int * max(len(block_idxs), 1))(*block_idxs)
+        with torch.cuda.device(lr.device):
+            hip.check(L.ifl_rrdb_encode(hip._ptr(params), nb, idx, len(block_idxs), hip._ptr(ws), hip._ptr(lr), hip._ptr(up1),
+                                        hip._ptr(up2), hip._ptr(up4), hip._ptr(up0), hip._ptr(out), hip._ptr(blocks),
+                                        B, H, W, hip._stream()), "ifl_rrdb_encode")
+        res = {'last_lr_fea': up1, 'fea_up1': up1, 'fea_up2': up2, 'fea_up4': up4, 'fea_up8': None, 'fea_up16': None,
+               'fea_up32': None, 'out': out}
+        if up0 is not None:
+            res['fea_up0'] = up0
+        for i, k in enumerate(block_idxs):
+            res["block_{}".format(k)] = blocks[i]
+        return res
+
     def rrdbPreprocessing(self, lr):
+        concat_on = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'concat']) or False
+        upn1 = opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False
+        if not self._needs_autograd() and concat_on and not upn1:
+            return self._rrdb_hip(lr)
+        # training of the encoder (autograd) still runs on PyTorch-ROCm ops: the backward kernels are not built yet
+        if not lr.is_cuda:
+            raise hip.InterflowHipError(f"rrdbPreprocessing: tensor is on {lr.device}; there is no CPU path")
         rrdbResults = self.RRDB(lr, get_steps=True)
         block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []
         if len(block_idxs) > 0:

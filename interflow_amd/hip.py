@@ -71,6 +71,19 @@ def lib():
     L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    L.ifl_rrdb_conv_count.argtypes = [c_int]
+    L.ifl_rrdb_conv_count.restype = c_int
+    L.ifl_rrdb_param_floats.argtypes = [c_int]
+    L.ifl_rrdb_param_floats.restype = c_int64
+    L.ifl_rrdb_conv_desc.argtypes = [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), POINTER(c_int64)]
+    L.ifl_rrdb_conv_desc.restype = c_int
+    L.ifl_rrdb_ws_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    L.ifl_rrdb_ws_bytes.restype = c_int64
+    L.ifl_rrdb_ws_init.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_rrdb_ws_init.restype = c_int
+    L.ifl_rrdb_encode.argtypes = [c_void_p, c_int, POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    L.ifl_rrdb_encode.restype = c_int
     L.ifl_quantize_u8_nhwc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_quantize_u8_nhwc.restype = c_int
     L.ifl_set_schedule.argtypes = [c_int, c_int, c_int]
@@ -91,7 +104,8 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_cond_prepare", "ifl_flow_pass",
-           "ifl_quantize_u8_nhwc")
+           "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 

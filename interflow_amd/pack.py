@@ -168,3 +168,47 @@ def pack_flow(prm, kinds, pfx="", training=False):
         layers[i].sum_logs = sl
         layers[i].sum_log_s = ss
     return params, layers
+
+
+# ------------------------------------------------------------------------------------- conditioning encoder
+def pack_conv_generic(w, cin_pad, cout_pad):
+    """nn.Conv2d weight [Cout, Cin, kh, kw] -> convg.hip fragment order
+    [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][h][i][e], zero-padded to (cout_pad, cin_pad)."""
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    wp = np.zeros((cout_pad, cin_pad, taps), F32)
+    wp[:cout, :cin] = w.reshape(cout, cin, taps)
+    mt = 2 if cout_pad % 64 == 0 else 1
+    g = cout_pad // (32 * mt)
+    wp = wp.reshape(g, mt, 32, cin_pad // 32, 4, 2, 4, taps)          # g mt i chunk kq h e tap
+    return np.ascontiguousarray(wp.transpose(0, 3, 7, 4, 1, 5, 2, 6)).reshape(-1)
+
+
+def rrdb_conv_names(nb):
+    """State-dict prefixes of the encoder's convolutions in execution order (RRDBNet_arch.py:85-125)."""
+    names = ["conv_first"]
+    for k in range(nb):
+        for r in (1, 2, 3):
+            names += [f"RRDB_trunk.{k}.RDB{r}.conv{c}" for c in (1, 2, 3, 4, 5)]
+    return names + ["trunk_conv", "upconv1", "upconv2", "HRconv", "conv_last"]
+
+
+def pack_rrdb(prm, nb, pfx=""):
+    """prm: RRDBNet state dict as numpy arrays -> packed float32 block for ifl_rrdb_encode."""
+    import ctypes
+    L = hip.lib()
+    names = rrdb_conv_names(nb)
+    assert len(names) == L.ifl_rrdb_conv_count(nb)
+    out = np.zeros(L.ifl_rrdb_param_floats(nb), F32)
+    cin, cout = ctypes.c_int(), ctypes.c_int()
+    wo, bo = ctypes.c_int64(), ctypes.c_int64()
+    for i, name in enumerate(names):
+        hip.check(L.ifl_rrdb_conv_desc(nb, i, ctypes.byref(cin), ctypes.byref(cout), ctypes.byref(wo), ctypes.byref(bo)),
+                  "ifl_rrdb_conv_desc")
+        w = prm[f"{pfx}{name}.weight"].astype(F32)
+        b = prm[f"{pfx}{name}.bias"].astype(F32)
+        assert w.shape[0] <= cout.value and w.shape[1] <= cin.value, (name, w.shape, cin.value, cout.value)
+        packed = pack_conv_generic(w, cin.value, cout.value)
+        out[wo.value:wo.value + packed.size] = packed
+        out[bo.value:bo.value + b.size] = b
+    return out
