@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cond-reuse", dest="cond_reuse", action="store_false",
                     help="skip the secondary measurement with the conditioning-only convs shared by encode and decode")
+    ap.add_argument("--no-bf16", dest="bf16", action="store_false",
+                    help="skip the secondary measurement with the bf16 variant of the dominant convolution")
     ap.add_argument("--breakdown", action="store_true",
                     help="after the timed region also run the steps on one stream and time every kernel (extra fields)")
     args = ap.parse_args()
@@ -144,6 +146,25 @@ def main():
             barrier()
             reuse_elapsed = shard.max_over_ranks(time.perf_counter() - t2, dist, dev)
             assert torch.equal(xr2, xr)
+        bf16 = None
+        if args.bf16:
+            # Secondary figure (never `value`): BASELINE.json configs[4]'s arithmetic on this workload -- the conditioning
+            # part of the coupling networks' first conv and fFeatures' 1x1 on the bf16 matrix cores, fp32 elsewhere.
+            model.flow_upsampler.conv_dtype = "bf16"
+            step(); step()
+            barrier()
+            hip.prof_enable([hip.K_CONV1_FT_L1])
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                ob = step()
+            barrier()
+            bf_elapsed = shard.max_over_ranks(time.perf_counter() - t3, dist, dev)
+            b_ms, b_n = hip.prof_read(hip.K_CONV1_FT_L1)
+            hip.prof_enable([])
+            model.flow_upsampler.conv_dtype = "fp32"
+            bf16 = {"elapsed": bf_elapsed, "dom_ms": b_ms, "dom_n": b_n,
+                    "round_trip_err": float((ob[2] - x).abs().max()),
+                    "z_rel_err_vs_fp32": float((ob[0] - z).abs().max() / z.abs().max())}
         if args.breakdown:
             # (1) the same steps with everything on ONE stream: kernels strictly one after another, so the dominant
             #     kernel's duration is free of time-sharing with the per-step chain; (2) one step with every kernel timed
@@ -217,6 +238,16 @@ def main():
                                  "note": "secondary, NOT the metric: same encode+decode, but the z-independent first conv of "
                                          "the coupling networks is computed once per step for both passes "
                                          "(ifl_cond_prepare); 0.54 of the reference's FLOPs are executed"}
+        if bf16:
+            fl = flops_total / max(bf16["dom_n"], 1)
+            res["bf16_conv1"] = {"value": world * B * args.steps / bf16["elapsed"], "unit": "patches/s",
+                                 "ms_per_step": bf16["elapsed"] / args.steps * 1e3, "dtype": "bf16 operands / f32 accumulate in "
+                                 "conv1_ft, f32 elsewhere",
+                                 "conv1_ft_bf16_kernel<1>": {"avg_launch_ms": bf16["dom_ms"] / max(bf16["dom_n"], 1),
+                                                             "achieved_tflops": fl / (bf16["dom_ms"] / max(bf16["dom_n"], 1) * 1e-3) / 1e12,
+                                                             "peak_tflops": 2500.0},
+                                 "z_rel_err_vs_fp32": bf16["z_rel_err_vs_fp32"], "roundtrip_max_abs_err": bf16["round_trip_err"],
+                                 "note": "secondary, NOT the metric (BASELINE.json configs[4] arithmetic on the configs[1] workload)"}
         if serial:
             res["serial_schedule"] = serial
             res["serial_schedule"]["dominant_tflops_alone"] = flops_launch / (serial["dominant_avg_launch_ms"] * 1e-3) / 1e12

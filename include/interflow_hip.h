@@ -61,7 +61,9 @@ enum {
     IFL_F_AN2A = 8, IFL_F_AN2F = 9,
     IFL_F_W3A = 10, IFL_F_W3F = 11,  /* Conv2dZeros 3x3, rows grouped as (shift,shift,scale,scale)  */
     IFL_F_B3A = 12, IFL_F_B3F = 13,  /* its bias and exp(3*logs) per accumulator element            */
-    IFL_F_COUNT = 14
+    IFL_F_W1A_BF16 = 14, IFL_F_W1F_BF16 = 15,   /* bf16 copies of the conditioning part of W1A / W1F (2 per float slot)  */
+    IFL_F_W2F_BF16 = 16,                        /* bf16 copy of fFeatures' 1x1 conv, accumulator-as-operand k order       */
+    IFL_F_COUNT = 17
 };
 int64_t ifl_step_param_floats(int C, int has_coupling);
 int64_t ifl_step_field_off(int C, int field);
@@ -106,8 +108,14 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
  * bit for bit, to ifl_flow_encode / ifl_flow_decode (same kernels, same order of operations).
  * ifl_flow_pass(decode = 0/1, flags = 0) is ifl_flow_encode / ifl_flow_decode.                                      */
 #define IFL_FLOW_COND_PREPARED 1
+/* IFL_FLOW_BF16_CONV1 (BASELINE.json configs[4]: "bf16 coupling-NN convs with fp32 ActNorm/logdet"): the conditioning part
+ * of both coupling networks' first conv and fFeatures' 1x1 conv -- 93 % of the path's FLOPs -- run on the bf16 matrix
+ * cores (operands rounded to bf16, fp32 accumulation); everything else stays fp32.  Pass it to ifl_cond_prepare and to
+ * every ifl_flow_pass that does not use IFL_FLOW_COND_PREPARED.  Encode and decode still invert each other to fp32
+ * accuracy; against the fp32 reference the outputs differ by the bf16 rounding (tolerance: tests/test_gpu_parity.py). */
+#define IFL_FLOW_BF16_CONV1 2
 int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
-                     void* stream);
+                     int flags, void* stream);
 int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src, float* dst,
                   const float* logdet_in, float* logdet_out, int B, int H, int W, float eps, int decode, int flags,
                   void* stream);

@@ -85,6 +85,9 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
         case IFL_F_W3F: return o.w3[1];
         case IFL_F_B3A: return o.b3[0];
         case IFL_F_B3F: return o.b3[1];
+        case IFL_F_W1A_BF16: return o.w1b[0];
+        case IFL_F_W1F_BF16: return o.w1b[1];
+        case IFL_F_W2F_BF16: return o.w2b;
     }
     return -1;
 }
@@ -353,7 +356,7 @@ int make_plan(const ifl_layer* layers, int n_layers, CondPlan* p)
 
 // phase 1 of one level: chunks of IFL_P1_CHUNK steps in the order given by `reverse`; event e0 + chunk index marks each
 int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* params, bool reverse, hipStream_t st,
-                  hipEvent_t* ev, int chunk_override = 0)
+                  hipEvent_t* ev, int bf16, int chunk_override = 0)
 {
     const IflLevelWs& lv = w.lv[lvl];
     const int n = plan.n[lvl];
@@ -367,7 +370,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
         for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
         int rc;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, lvl + 1, st); }
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, lvl + 1, bf16, st); }
         if (rc) return rc;
         if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
     }
@@ -429,7 +432,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
 }
 
-int run_flow(bool decode, bool prepared, const ifl_layer* layers, int n_layers, const float* params, void* ws,
+int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int n_layers, const float* params, void* ws,
              const float* src, float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps,
              hipStream_t st)
 {
@@ -456,7 +459,7 @@ int run_flow(bool decode, bool prepared, const ifl_layer* layers, int n_layers, 
     // phase 1 in the order the chain consumes the levels
     for (int k = 0; k < IFL_MAX_LEVELS && !prepared; ++k) {
         const int lvl = decode ? IFL_MAX_LEVELS - 1 - k : k;
-        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev))) return rc;
+        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev, bf16))) return rc;
     }
     if (use_aux) IFL_HIP(hipEventRecord(f->aux_done, f->aux));
     else if (G > 1) IFL_HIP(hipEventRecord(f->fork, st));        // groups start after phase 1 on the caller's stream
@@ -497,7 +500,7 @@ extern "C" int ifl_flow_encode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    return run_flow(false, false, layers, n_layers, params, ws, x, z, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
+    return run_flow(false, false, 0, layers, n_layers, params, ws, x, z, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -508,12 +511,13 @@ extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const floa
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && x && z && logdet_out, IFL_EINVAL, "null pointer");
-    return run_flow(true, false, layers, n_layers, params, ws, z, x, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
+    return run_flow(true, false, 0, layers, n_layers, params, ws, z, x, logdet_in, logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
 extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
-                                void* stream)
+                                int flags, void* stream)
 {
+    IFL_CHECK_ARG((flags & ~IFL_FLOW_BF16_CONV1) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
     int rc = check_shape(B, H, W);
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
@@ -523,7 +527,7 @@ extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const flo
     CondPlan plan;
     if ((rc = make_plan(layers, n_layers, &plan))) return rc;
     for (int lvl = 0; lvl < IFL_MAX_LEVELS; ++lvl)      // one launch per level: all conditional steps at once
-        if ((rc = launch_phase1(w, lvl, plan, params, false, (hipStream_t)stream, nullptr, IFL_MAX_COND))) return rc;
+        if ((rc = launch_phase1(w, lvl, plan, params, false, (hipStream_t)stream, nullptr, (flags & IFL_FLOW_BF16_CONV1) != 0, IFL_MAX_COND))) return rc;
     return 0;
 }
 
@@ -535,8 +539,8 @@ extern "C" int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float*
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && src && dst && logdet_out, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG((flags & ~IFL_FLOW_COND_PREPARED) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
-    return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, layers, n_layers, params, ws, src, dst, logdet_in,
+    IFL_CHECK_ARG((flags & ~(IFL_FLOW_COND_PREPARED | IFL_FLOW_BF16_CONV1)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
+    return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, (flags & IFL_FLOW_BF16_CONV1) != 0, layers, n_layers, params, ws, src, dst, logdet_in,
                     logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
@@ -565,7 +569,7 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
         IflStepList one{};
         one.off[0] = layer->param_off;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, lvl + 1, st); }
+          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, lvl + 1, 0, st); }
         if (rc) return rc;
     }
     rc = reverse ? step_decode(*layer, params, w, lv, lv.h2, slots, constant, eps, st)

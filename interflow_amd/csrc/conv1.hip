@@ -249,6 +249,198 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
     }
 }
 
+
+// ---- bf16 variant of phase 1 (BASELINE.json configs[4]: bf16 coupling-network convs, fp32 ActNorm / log-det) ------------
+// Same tiling and data flow as conv1_ft_kernel; the two GEMMs run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate):
+//   * the conditioning patch is converted fp32 -> bf16 (round to nearest even, v_cvt_pk_bf16_f32) while it is staged
+//     into LDS: 32 channels = 64 B per pixel, pixel stride 80 B (16-byte reads of consecutive pixels hit disjoint banks);
+//   * weights are bf16 copies in fragment order (lane (i, h) holds W[out i][k = 8h .. 8h+7] of a 16-channel k-step);
+//   * accumulation, ActNorm, ReLU and the stores stay fp32; fFeatures' 1x1 conv takes the fp32 accumulators, rounded to
+//     bf16, as its B operand in registers (the k order inside a step is that of the accumulator rows, and the 1x1 weights
+//     are packed to match).
+// The result differs from the fp32 path by bf16 rounding of the operands (tolerance stated in tests/test_gpu_parity.py);
+// encode and decode still invert each other to fp32 accuracy, because both directions compute the same network outputs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CSB = 80;                       // LDS pixel stride in bytes of a 32-channel bf16 chunk
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int LVL>
+__global__ __launch_bounds__(256, 2)
+void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
+                          const float* __restrict__ params, IflStepList steps, IflStepOff off, IflGeom g)
+{
+    constexpr int NT = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LD_SLOTS * 32 * CSB];
+    const int tile = blockIdx.x, step = blockIdx.z;
+    const IflTile t = ifl_tile(g, tile);
+    if (!t.active) return;
+    const int b = blockIdx.y;
+    const float* prm = params + steps.off[step];
+    float* h2P = h2all + (int64_t)step * h2_step_stride;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int net = wave & 1, part = wave >> 1;
+    const int W2 = g.W + 2;
+
+    int a0[NT];
+    int64_t opix[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int idx = t.s + part * 64 + n * 32 + j;
+        bool valid = idx < t.npx;
+        int idc = valid ? idx : t.npx - 1;
+        int ty = idc / t.bwb, tx = idc - ty * t.bwb;
+        a0[n] = ((ty - t.y_first - 1) * t.PW + tx) * CSB + 16 * h;
+        opix[n] = valid ? ((int64_t)(b * (g.H + 2) + ty + 1) * (g.W + 2) + t.x0 + tx + 1) : -1;
+    }
+
+    const float* ft_b = ftP + (int64_t)b * (g.H + 2) * W2 * IFL_FT;
+    int srcoff[LD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LD_SLOTS; ++i) {
+        int idx = tid + i * 256;
+        int p = idx >> 3, q = idx & 7;
+        int r = p / t.PW, c = p - r * t.PW;
+        srcoff[i] = (p < t.PP) ? (((t.y_first + 1 + r) * W2 + t.x0 + c) * IFL_FT + q * 4) : 0;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    constexpr int WD = 6;
+    constexpr int ITERS = 18;                 // 9 taps x 2 k-steps of 16 channels per chunk
+    static_assert(ITERS % WD == 0, "ring slots must be compile-time");
+    const bf16x8* wnet = (const bf16x8*)(prm + off.w1b[net]) + lane;          // block bi at wnet[bi * 64]
+    bf16x8 wq[WD][2];
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wq[d][m] = wnet[(d * 2 + m) * 64];
+
+    f32x4 stage[LD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)(ft_b + srcoff[i]);
+
+    for (int cc = 0; cc < NCC; ++cc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LD_SLOTS; ++i) {
+            int idx = tid + i * 256;
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)stage[i][e];
+            *(bf16x4*)&lds[(idx >> 3) * CSB + (idx & 7) * 8] = v;
+        }
+        __syncthreads();
+        if (cc + 1 < NCC) {
+#pragma unroll
+            for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)(ft_b + srcoff[i] + (cc + 1) * IFL_CK);
+        }
+        const bf16x8* wc = wnet + (int64_t)cc * (ITERS * 2 * 64);
+        bf16x8 xb[2][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xb[0][n] = *(const bf16x8*)(lds + a0[n]);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it + 1 < ITERS) {
+                const int tap = (it + 1) >> 1, ks = (it + 1) & 1;
+                const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * CSB;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xb[(it + 1) & 1][n] = *(const bf16x8*)(lds + a0[n] + tapoff + ks * 32);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(wq[it % WD][m], xb[it & 1][n], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) wq[it % WD][m] = wc[((it + WD) * 2 + m) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    if (net == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (opix[n] < 0) continue;
+            float* dst = h2P + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(f32x4*)(dst + m * 32 + gq * 8) = f32x4{acc[m][n][gq * 4], acc[m][n][gq * 4 + 1],
+                                                             acc[m][n][gq * 4 + 2], acc[m][n][gq * 4 + 3]};
+        }
+        return;
+    }
+    // fFeatures: ActNorm + ReLU (fp32), 1x1 conv on the bf16 matrix cores straight from the accumulators, ActNorm + ReLU
+    const float* an1 = prm + off.an1[1];
+    const float* an2 = prm + off.an2[1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4 bb[4], ss[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bb[q] = *(const f32x4*)(an1 + (m * 2 + h) * 16 + q * 4);
+            ss[q] = *(const f32x4*)(an1 + 64 + (m * 2 + h) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[m][n][r] + bb[r >> 2][r & 3]) * ss[r >> 2][r & 3];
+                acc[m][n][r] = v > 0.f ? v : 0.f;
+            }
+    }
+    const bf16x8* w2 = (const bf16x8*)(prm + off.w2b) + lane;      // block ((m2*2 + m)*2 + s) at w2[.. * 64]
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x16 y[2];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[m2][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 xk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xk[e] = (__bf16)acc[m][n][8 * s2 + e];
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma_bf16(w2[((m2 * 2 + m) * 2 + s2) * 64], xk, y[m2]);
+            }
+        if (opix[n] >= 0) {
+            float* dst = h2P + IFL_HID + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 bb = *(const f32x4*)(an2 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 ss = *(const f32x4*)(an2 + 64 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (y[m2][gq * 4 + e] + bb[e]) * ss[e];
+                        o[e] = v > 0.f ? v : 0.f;
+                    }
+                    *(f32x4*)(dst + m2 * 32 + gq * 8) = o;
+                }
+        }
+    }
+}
+
 // ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
 // 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
 // of 8 with zero weights).
@@ -322,10 +514,16 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
 }  // namespace
 
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
-                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, hipStream_t st)
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, int bf16, hipStream_t st)
 {
     if (nsteps <= 0) return 0;
     dim3 grid(g.ntiles, B, nsteps), block(256);
+    if (bf16) {
+        if (level == 1) hipLaunchKernelGGL(conv1_ft_bf16_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+        else hipLaunchKernelGGL(conv1_ft_bf16_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+        IFL_LAUNCH_CHECK();
+        return 0;
+    }
     if (level == 1) hipLaunchKernelGGL(conv1_ft_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
     else hipLaunchKernelGGL(conv1_ft_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
     IFL_LAUNCH_CHECK();

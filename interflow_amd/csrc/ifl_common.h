@@ -65,6 +65,7 @@ static inline __host__ __device__ int ifl_na(int C) { return ifl_cdiv(C / 2, 8);
 struct IflStepOff {       // float offsets inside one step's block
     int64_t anic_fwd, anic_inv;
     int64_t w1[2], an1[2], w2[2], an2[2], w3[2], b3[2];     // [0] = fAffine, [1] = fFeatures
+    int64_t w1b[2], w2b;      // bf16 copies for the bf16 variant of conv1_ft: first conv over ft (both nets), fFeatures' 1x1
     int64_t total;
 };
 
@@ -85,7 +86,10 @@ static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_couplin
         o.w3[1] = take((int64_t)ifl_nf(C) * 16 * 9 * IFL_HID);
         o.b3[0] = take(ifl_na(C) * 32);
         o.b3[1] = take(ifl_nf(C) * 32);
-    }
+        for (int n = 0; n < 2; ++n) o.w1b[n] = take((int64_t)IFL_HID * 9 * IFL_FT / 2);      // 2 bf16 per float slot
+        o.w2b = take(IFL_HID * IFL_HID / 2);
+        take(4096);                                                // pad: the weight prefetch ring reads past a field's end
+    } else { o.w1b[0] = o.w1b[1] = o.w2b = 0; }
     o.total = p;
     return o;
 }
@@ -158,7 +162,7 @@ int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* w
                int64_t n, hipStream_t st);
 // conv1.hip
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
-                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, hipStream_t st);
+                   int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, int bf16, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine

@@ -284,6 +284,14 @@ class FlowUpsamplerNet(nn.Module):
         self.scaleH, self.scaleW = 160 / H, 160 / W
         self._packed = None
         self.affine_eps = opt_get(opt, ['network_G', 'flow', 'CondAffineSeparatedAndCond', 'eps'], 0.0001)
+        # "fp32" (reference arithmetic) or "bf16": the conditioning part of the coupling networks' first conv and
+        # fFeatures' 1x1 conv on the bf16 matrix cores, fp32 everywhere else (BASELINE.json configs[4]); not a state-dict item
+        self.conv_dtype = "fp32"
+
+    def _flags(self):
+        if self.conv_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"conv_dtype {self.conv_dtype!r}: expected 'fp32' or 'bf16'")
+        return hip.FLOW_BF16_CONV1 if self.conv_dtype == "bf16" else 0
 
     # ---- packed parameters, rebuilt when any parameter changes ----
     def _pack(self, device):
@@ -365,8 +373,8 @@ class FlowUpsamplerNet(nn.Module):
         with torch.cuda.device(dev):
             self._load_cond(ws, enc, batch, H, W)
             hip.check(hip.lib().ifl_cond_prepare(layers, len(layers), hip._ptr(params), ws.ptr, batch, H, W,
-                                                 hip._stream()), "ifl_cond_prepare")
-        return PreparedCond(rrdbResults, ws, ws.generation, self._packed[0], enc, (batch, H, W))
+                                                 self._flags(), hip._stream()), "ifl_cond_prepare")
+        return PreparedCond(rrdbResults, ws, ws.generation, (self._packed[0], self.conv_dtype), enc, (batch, H, W))
 
     def _run(self, src, rrdbResults, logdet, test_input_size, decode):
         src = hip._dev_f32(src, "flow input")
@@ -386,13 +394,13 @@ class FlowUpsamplerNet(nn.Module):
         L = hip.lib()
         ld_in = _as_logdet(logdet, B, src.device)
         ld_out = torch.empty(B, dtype=torch.float32, device=src.device)
-        prepared = isinstance(rrdbResults, PreparedCond) and rrdbResults.usable(ws, self._packed[0], feats, (B, H, W))
+        prepared = isinstance(rrdbResults, PreparedCond) and rrdbResults.usable(ws, (self._packed[0], self.conv_dtype), feats, (B, H, W))
         with torch.cuda.device(src.device):
             if not prepared:
                 self._load_cond(ws, feats, B, H, W)
             hip.check(L.ifl_flow_pass(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
                                       hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps),
-                                      1 if decode else 0, hip.FLOW_COND_PREPARED if prepared else 0, hip._stream()),
+                                      1 if decode else 0, hip.FLOW_COND_PREPARED if prepared else self._flags(), hip._stream()),
                       "ifl_flow_pass")
         return out, ld_out
 

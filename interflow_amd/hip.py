@@ -17,10 +17,11 @@ LIB_PATH = os.path.join(_HERE, "libinterflow_hip.so")
 
 IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
 FLOW_COND_PREPARED = 1
+FLOW_BF16_CONV1 = 2
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
- F_W3A, F_W3F, F_B3A, F_B3F) = range(14)
+ F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16) = range(17)
 
 
 class IflLayer(Structure):
@@ -59,7 +60,7 @@ def lib():
                  c_int, c_int, c_int, c_float, c_void_p]
     L.ifl_flow_encode.argtypes = flow_args
     L.ifl_flow_decode.argtypes = flow_args
-    L.ifl_cond_prepare.argtypes = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    L.ifl_cond_prepare.argtypes = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_flow_pass.argtypes = flow_args[:-1] + [c_int, c_int, c_void_p]
     L.ifl_flow_step.argtypes = [POINTER(IflLayer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]

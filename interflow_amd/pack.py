@@ -59,6 +59,32 @@ def _pack_conv1(wt, zoff, kz):
     return np.concatenate(out)
 
 
+def to_bf16_bits(a):
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)."""
+    u = np.ascontiguousarray(a, F32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def _as_float_slots(bits16):
+    """uint16 array (even length) -> float32 view, two bf16 per float slot of the parameter block."""
+    return np.ascontiguousarray(bits16).view(F32)
+
+
+def _pack_conv1_bf16(wt, zoff):
+    """Conditioning part of wt [64, Cin, 3, 3] -> [cc][tap][ks][mt][h][i][j], in channel = cc*32 + ks*16 + 8h + j, as bf16."""
+    wft = wt[:, zoff:zoff + N_RRDB_CH].reshape(2, 32, 10, 2, 2, 8, 9)            # mt i cc ks h j tap
+    return _as_float_slots(to_bf16_bits(np.ascontiguousarray(wft.transpose(2, 6, 3, 0, 4, 1, 5)).reshape(-1)))
+
+
+def _pack_conv2_bf16(w2):
+    """w2 [64,64,1,1] -> [m2][m][s][h][i][j] = W[m2*32+i][m*32 + 16s + 8(j>>2) + 4h + (j&3)] (the accumulator's row order
+    when a 32x32 tile is fed back as the B operand of v_mfma_f32_32x32x16_bf16), as bf16."""
+    w = w2.reshape(HIDDEN, HIDDEN)
+    m2, m, s_, h, i, j = np.meshgrid(np.arange(2), np.arange(2), np.arange(2), np.arange(2), np.arange(32), np.arange(8),
+                                     indexing="ij")
+    return _as_float_slots(to_bf16_bits(w[m2 * 32 + i, m * 32 + 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)].reshape(-1)))
+
+
 def _pack_actnorm64(bias, logs):
     b = bias.reshape(-1)[_ACC]
     s = np.exp(logs.reshape(-1).astype(F32))[_ACC]
@@ -141,6 +167,10 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
                                  prm[q + "4.logs"].astype(F32), C, net)
             put(fw3, wp)
             put(fb3, bp)
+            put(hip.F_W1A_BF16 if net == 0 else hip.F_W1F_BF16,
+                _pack_conv1_bf16(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
+            if net == 1:
+                put(hip.F_W2F_BF16, _pack_conv2_bf16(prm[q + "2.weight"].astype(F32)))
     return float(np.sum(logs, dtype=F32)), float(sum_log_s)
 
 

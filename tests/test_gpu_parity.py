@@ -363,3 +363,58 @@ def test_rrdb_encoder_vs_oracle(golden_dir, sd_np, sd, model, B, H, W):
         model.arch.rrdbPreprocessing(torch.zeros(1, 3, 10, 8, device=dev()))          # H % 4 != 0
     with pytest.raises(RuntimeError), torch.no_grad():
         model.arch.rrdbPreprocessing(torch.zeros(1, 3, 8, 4, device=dev()))           # fea_up0 would be empty (RRDBNet_arch.py:138)
+
+
+# ----------------------------------------------------------------------------- bf16 coupling-network convs (configs[4])
+BF16_TOL_Z, BF16_TOL_LD = 1e-2, 1e-4      # rel. to the tensor's max magnitude (bf16 operands carry 8 significant bits);
+                                          # measured on MI355X at 160x160: z 3.7e-3, logdet 4.6e-6
+
+
+def test_bf16_conv1_against_reference_and_round_trip(golden_dir, sd_np, model):
+    """conv_dtype='bf16': the conditioning part of the coupling networks' first conv and fFeatures' 1x1 run on the bf16
+    matrix cores.  Against the fp32 reference outputs the tolerance is BF16_TOL_*; decode(encode(x)) stays at the fp32
+    tolerance because both directions evaluate the same networks; the prepared-conditioning path is bit-identical."""
+    g = load(golden_dir, "full160_seed0.npz", sd_np)
+    B, H = 2, 160
+    x = t(synth.synth_images(1, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(2, B, H, H).items()}
+    fu = model.flow_upsampler
+    z32, ld32 = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    fu.conv_dtype = "bf16"
+    try:
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        e1 = rel_close(z, g["z"], BF16_TOL_Z, what="bf16 z vs reference")
+        e2 = rel_close(ld, g["ld"], BF16_TOL_LD, what="bf16 logdet vs reference")
+        assert not torch.equal(z, z32), "bf16 path produced the fp32 result: the flag is not reaching the kernel"
+        xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        e3 = rel_close(xr, x, RTOL, what="bf16 decode(encode(x))")
+        rel_close(-ldr, ld, RTOL, what="bf16 logdet cancels")
+        prep = fu.prepare_cond(feats, B, H, H)
+        zp, ldp = model(x, None, lr_enc=prep, add_gt_noise=False, calc_loss=False)
+        assert torch.equal(zp, z) and torch.equal(ldp, ld)
+        print(f"bf16 rel errs: z {e1:.2e} logdet {e2:.2e} round trip {e3:.2e}")
+        # a preparation made in one precision is not used by the other
+        fu.conv_dtype = "fp32"
+        zq, _ = model(x, None, lr_enc=prep, add_gt_noise=False, calc_loss=False)
+        assert torch.equal(zq, z32)
+    finally:
+        fu.conv_dtype = "fp32"
+
+
+def test_bf16_512_patch(sd, model):
+    """BASELINE.json configs[4] shape: one 512x512 patch; bf16 against the fp32 HIP path and its own inverse."""
+    B, H = 1, 512
+    x = t(synth.synth_images(71, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(72, B, H, H).items()}
+    fu = model.flow_upsampler
+    z32, ld32 = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False, )
+    x32, _ = model(z32, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+    rel_close(x32, x, RTOL, what="fp32 512 round trip")
+    fu.conv_dtype = "bf16"
+    try:
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        rel_close(z, z32, BF16_TOL_Z, what="bf16 z vs fp32"); rel_close(ld, ld32, BF16_TOL_LD, what="bf16 logdet vs fp32")
+        xr, _ = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+        rel_close(xr, x, RTOL, what="bf16 512 round trip")
+    finally:
+        fu.conv_dtype = "fp32"
