@@ -73,10 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cond-reuse", dest="cond_reuse", action="store_false",
-                    help="skip the secondary measurement with the conditioning-only convs shared by encode and decode")
-    ap.add_argument("--no-bf16", dest="bf16", action="store_false",
-                    help="skip the secondary measurement with the bf16 variant of the dominant convolution")
+    ap.add_argument("--extras", action="store_true",
+                    help="after the timed region also measure two secondary figures (never `value`): conditioning reuse "
+                         "between encode and decode, and the bf16 variant of the dominant convolution")
     ap.add_argument("--breakdown", action="store_true",
                     help="after the timed region also run the steps on one stream and time every kernel (extra fields)")
     args = ap.parse_args()
@@ -128,7 +127,7 @@ def main():
         z, ld, xr, ldr = out
         err = float((xr - x).abs().max())
         assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
-        if args.cond_reuse:
+        if args.extras:
             # Secondary figure (never `value`): the conditioning-only part of the coupling networks computed ONCE per
             # step (ifl_cond_prepare) and used by both the encode and the decode of that step, as
             # InterpFlow.weighted_interpolate_image / generate.py do.  Outputs are bit-identical.
@@ -147,7 +146,7 @@ def main():
             reuse_elapsed = shard.max_over_ranks(time.perf_counter() - t2, dist, dev)
             assert torch.equal(xr2, xr)
         bf16 = None
-        if args.bf16:
+        if args.extras:
             # Secondary figure (never `value`): BASELINE.json configs[4]'s arithmetic on this workload -- the conditioning
             # part of the coupling networks' first conv and fFeatures' 1x1 on the bf16 matrix cores, fp32 elsewhere.
             model.flow_upsampler.conv_dtype = "bf16"
@@ -232,7 +231,7 @@ def main():
             "path_tflops": 213.1e9 * B * args.steps / elapsed / 1e12,
             "roundtrip_max_abs_err": err,
         }
-        if args.cond_reuse:
+        if args.extras:
             res["cond_reuse"] = {"value": world * B * args.steps / reuse_elapsed, "unit": "patches/s",
                                  "ms_per_step": reuse_elapsed / args.steps * 1e3,
                                  "note": "secondary, NOT the metric: same encode+decode, but the z-independent first conv of "

@@ -268,6 +268,7 @@ static int check_layers(const ifl_layer* layers, int n_layers)
 #define IFL_MAX_GROUPS 4
 #define IFL_P1_CHUNK 8
 namespace {
+int env_int(const char* name, int dflt);
 constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
 struct ForkCtx {
     bool ok = false;
@@ -285,7 +286,7 @@ int fork_ctx(ForkCtx** out)
     if (!f.ok) {
         int lo = 0, hi = 0;
         IFL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent
-        IFL_HIP(hipStreamCreateWithPriority(&f.aux, hipStreamNonBlocking, lo));
+        IFL_HIP(hipStreamCreateWithPriority(&f.aux, hipStreamNonBlocking, env_int("IFL_AUX_PRIO_HIGH", 0) ? hi : lo));
         for (int i = 0; i < IFL_MAX_GROUPS - 1; ++i) {
             IFL_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
             IFL_HIP(hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming));
