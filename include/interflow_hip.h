@@ -156,6 +156,28 @@ int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, f
 int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,
              int B, int64_t n_per_sample, void* stream);
 
+/* ---- generic convolution primitives (the building blocks of the encoder and of the training path) ----
+ * Tensors are "ringed channels-last" planes [B][h+2][w+2][stride] float32 whose one-pixel ring is zero (the 'same' padding
+ * of flow.py:27 / nn.Conv2d(padding=1)); a source or destination is a channel range [off, off+n) of such a buffer.
+ * ifl_conv2d: out = epilogue(conv(cat(src0, src1), w) + bias), stride 1, 3x3 (taps 9) or 1x1 (taps 1).  Channel counts are
+ * multiples of 32 (pad with zero channels / zero weights).  w is in fragment order: element
+ *   [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][half h][i][e] = W[out = group*32*MT + mt*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap]
+ * with MT = 2 when cout % 64 == 0, else 1.  Epilogue: act (0 none, 1 LeakyReLU 0.2, 2 ReLU), then v = v*alpha + res1,
+ * then v = v*beta + res2 (each optional).  Only interior pixels are written.
+ * The data gradient of a convolution is ifl_conv2d with the transposed, spatially flipped weights.
+ * ifl_conv2d_wgrad: dW[co][ci0*32 + ci][tap] += sum_{b,px} dy[b,px][co] * x[b,px+tap][ci] for the cin channels of one
+ * source (dW row-major [cout][cin_total][taps], float atomics: zero it first; cout in {32,64,96}).                       */
+typedef struct ifl_conv_desc {
+    const float* src[2]; int32_t src_stride[2], src_off[2], src_ch[2]; int32_t nsrc;
+    const float* w; const float* bias;
+    float* out; int32_t out_stride, out_off, cout, taps, act;
+    const float* res1; int32_t res1_stride, res1_off; float alpha;
+    const float* res2; int32_t res2_stride, res2_off; float beta;
+} ifl_conv_desc;
+int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream);
+int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin, const float* dy, int dy_stride, int dy_off, int cout,
+                     float* dW, int cin_total, int ci0, int taps, int B, int h, int w, void* stream);
+
 /* ---- conditioning encoder ----
  * RRDBNet.forward(get_steps=True) (RRDBNet_arch.py:85-148) followed by RRDBGlowNet.rrdbPreprocessing
  * (RRDBGlowNet_arch.py:217-246) for the shipped options (scale 4, nf 64, gc 32, stackRRDB concat): x [B,3,H,W] ->

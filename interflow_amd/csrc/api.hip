@@ -598,6 +598,38 @@ extern "C" int ifl_unsqueeze2d(const float* in, float* out, int B, int C, int H,
     return ifl_k_squeeze_nchw(in, out, B, C / (factor * factor), H * factor, W * factor, factor, 1, (hipStream_t)stream);
 }
 
+extern "C" int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(d && d->w && d->out && d->src[0], IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape B=%d h=%d w=%d", B, h, w);
+    IFL_CHECK_ARG(d->nsrc == 1 || (d->nsrc == 2 && d->src[1]), IFL_EINVAL, "nsrc=%d", d->nsrc);
+    IflConvArgs a{};
+    a.nsrc = d->nsrc;
+    for (int s = 0; s < d->nsrc; ++s) {
+        IFL_CHECK_ARG(d->src_ch[s] > 0 && d->src_ch[s] % 32 == 0 && d->src_off[s] % 4 == 0 && d->src_stride[s] % 4 == 0, IFL_EINVAL,
+                      "source %d: %d channels at offset %d, stride %d", s, d->src_ch[s], d->src_off[s], d->src_stride[s]);
+        a.src[s] = d->src[s]; a.src_stride[s] = d->src_stride[s]; a.src_off[s] = d->src_off[s]; a.src_chunks[s] = d->src_ch[s] / 32;
+        a.nchunks += d->src_ch[s] / 32;
+    }
+    IFL_CHECK_ARG(d->out_off % 4 == 0 && d->out_stride % 4 == 0, IFL_EINVAL, "destination offset/stride must be multiples of 4");
+    a.w = d->w; a.bias = d->bias;
+    a.out = d->out; a.out_stride = d->out_stride; a.out_off = d->out_off; a.cout = d->cout; a.taps = d->taps; a.act = d->act;
+    a.res1 = d->res1; a.res1_stride = d->res1_stride; a.res1_off = d->res1_off; a.alpha = d->alpha;
+    a.res2 = d->res2; a.res2_stride = d->res2_stride; a.res2_off = d->res2_off; a.beta = d->beta;
+    a.g = ifl_choose_geom(h, w);
+    return ifl_k_convg(a, B, (hipStream_t)stream);
+}
+
+extern "C" int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin, const float* dy, int dy_stride, int dy_off,
+                                int cout, float* dW, int cin_total, int ci0, int taps, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(x && dy && dW, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape B=%d h=%d w=%d", B, h, w);
+    IFL_CHECK_ARG(ci0 >= 0 && (ci0 * 32 + cin) <= cin_total, IFL_EINVAL, "channel range outside dW");
+    return ifl_k_wgrad(x, x_stride, x_off, cin, dy, dy_stride, dy_off, cout, dW, cin_total, ci0, taps, ifl_choose_geom(h, w), B,
+                       (hipStream_t)stream);
+}
+
 extern "C" int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream)
 {
     IFL_CHECK_ARG(B >= 0 && C >= 1 && H >= 0 && W >= 0, IFL_EINVAL, "bad shape");

@@ -162,3 +162,107 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
     IFL_LAUNCH_CHECK();
     return 0;
 }
+
+// ======================================================================================================================
+// Weight gradient of the generic convolution:  dW[co][ci][tap] = sum over images and pixels of dY[px][co] * X[px + tap][ci]
+// (torch.nn.grad.conv2d_weight for a stride-1 'same' conv).  GEMM with K = pixels: D[32 co][32 ci] += A[co][px] * B[px][ci]
+// on v_mfma_f32_32x32x2_f32, two pixels per instruction.
+//   workgroup  = one 32-channel input chunk (blockIdx.y) x a strided set of (image, pixel tile) pairs (blockIdx.x);
+//   LDS        = the tile's dY rows [128 px][cout], the chunk's X patch [(rows+2) x (bw+2) px][32 ch], the patch position
+//                of every tile pixel;
+//   wave w     = the (co tile, tap) pairs p = w, w+4, ...: one 32x32 accumulator each, kept in registers over all the
+//                workgroup's tiles and added to dW with float atomics once at the end.
+template <int CT, int TAPS>        // CT = cout / 32 (1..3)
+__global__ __launch_bounds__(256)
+void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __restrict__ DY, int dys, int dyoff,
+                  float* __restrict__ dW, int cin_total, int ci0, IflGeom g, int B)
+{
+    constexpr int NP = CT * TAPS, PPW = (NP + 3) / 4;            // pairs, pairs per wave
+    constexpr int DS = CT * 32 + 1;                               // dY row stride in LDS (odd: conflict-free column reads)
+    constexpr int XS = 33;
+    __shared__ float dy[IFL_MT * DS];
+    __shared__ float xp[IFL_PP_MAX * XS];
+    __shared__ int pos[IFL_MT];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.y;
+    const int W2 = g.W + 2;
+    const int64_t plane = (int64_t)(g.H + 2) * W2;
+
+    f32x16 acc[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int nwork = g.ntiles * B;
+    for (int wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+        const int b = wk / g.ntiles;
+        const IflTile t = ifl_tile(g, wk - b * g.ntiles);
+        if (!t.active) continue;
+        __syncthreads();                                          // previous tile fully consumed
+        // stage dY rows of the tile (zero for pixels past the band's end), their patch positions, and the X patch
+        for (int idx = tid; idx < IFL_MT * CT * 32; idx += 256) {
+            int p = idx / (CT * 32), c = idx - p * (CT * 32);
+            int pi = t.s + p;
+            float v = 0.f;
+            if (pi < t.npx) {
+                int ty = pi / t.bwb, tx = pi - ty * t.bwb;
+                v = DY[((int64_t)b * plane + (int64_t)(ty + 1) * W2 + t.x0 + tx + 1) * dys + dyoff + c];
+                if (c == 0) pos[p] = (ty - t.y_first - (TAPS == 9 ? 1 : 0)) * t.PW + tx + (TAPS == 9 ? 0 : 1);
+            } else if (c == 0) pos[p] = 0;
+            dy[p * DS + c] = v;
+        }
+        for (int idx = tid; idx < t.PP * 32; idx += 256) {
+            int p = idx >> 5, c = idx & 31;
+            int r = p / t.PW, cc = p - r * t.PW;
+            xp[p * XS + c] = X[((int64_t)b * plane + (int64_t)(t.y_first + 1 + r) * W2 + t.x0 + cc) * xs + xoff + chunk * 32 + c];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < IFL_MT / 2; ++kk) {
+            const int p = 2 * kk + h;
+            const int pp = pos[p];
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                const int pr = wave + 4 * q;
+                if (pr < NP) {                                   // wave-uniform
+                    const int ct = pr / TAPS, tap = pr - ct * TAPS;
+                    const int tapoff = TAPS == 9 ? (tap / 3) * t.PW + (tap % 3) : 0;
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy[p * DS + ct * 32 + j], xp[(pp + tapoff) * XS + j], acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // flush: accumulator element r of lane (j, h) is dW[co = ct*32 + (r&3) + 8*(r>>2) + 4*h][ci = chunk*32 + j][tap]
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pr = wave + 4 * q;
+        if (pr >= NP) continue;
+        const int ct = pr / TAPS, tap = pr - ct * TAPS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            atomicAdd(dW + ((int64_t)co * cin_total + (ci0 + chunk) * 32 + j) * TAPS + tap, acc[q][r]);
+        }
+    }
+}
+
+int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,
+                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st)
+{
+    IFL_CHECK_ARG(cin % 32 == 0 && cin > 0 && cout % 32 == 0 && cout >= 32 && cout <= 96, IFL_ENOTSUP,
+                  "wgrad: cin=%d cout=%d (cin a multiple of 32, cout 32, 64 or 96)", cin, cout);
+    IFL_CHECK_ARG(taps == 9 || taps == 1, IFL_EINVAL, "wgrad: taps=%d", taps);
+    int nwork = g.ntiles * B;
+    int gx = nwork < 48 ? nwork : 48;                             // tiles per workgroup bound the atomic traffic
+    dim3 grid(gx, cin / 32), block(256);
+#define IFL_WG(CT, T) hipLaunchKernelGGL((wgrad_kernel<CT, T>), grid, block, 0, st, X, xs, xoff, DY, dys, dyoff, dW, cin_total, ci0, g, B)
+    const int ct = cout / 32;
+    if (taps == 9) { if (ct == 1) IFL_WG(1, 9); else if (ct == 2) IFL_WG(2, 9); else IFL_WG(3, 9); }
+    else { if (ct == 1) IFL_WG(1, 1); else if (ct == 2) IFL_WG(2, 1); else IFL_WG(3, 1); }
+#undef IFL_WG
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

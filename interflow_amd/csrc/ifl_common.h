@@ -133,6 +133,8 @@ struct IflConvArgs {
     IflGeom g;
 };
 int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
+int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,
+                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st);
 IflGeom ifl_choose_geom(int H, int W);
 
 int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out);     // base may be NULL (size query)

@@ -29,6 +29,14 @@ class IflLayer(Structure):
                 ("sum_logs", c_float), ("sum_log_s", c_float)]
 
 
+class IflConvDesc(Structure):
+    _fields_ = [("src", c_void_p * 2), ("src_stride", c_int32 * 2), ("src_off", c_int32 * 2), ("src_ch", c_int32 * 2),
+                ("nsrc", c_int32), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("out_stride", c_int32),
+                ("out_off", c_int32), ("cout", c_int32), ("taps", c_int32), ("act", c_int32),
+                ("res1", c_void_p), ("res1_stride", c_int32), ("res1_off", c_int32), ("alpha", c_float),
+                ("res2", c_void_p), ("res2_stride", c_int32), ("res2_off", c_int32), ("beta", c_float)]
+
+
 class InterflowHipError(RuntimeError):
     pass
 
@@ -85,6 +93,11 @@ def lib():
     L.ifl_rrdb_encode.argtypes = [c_void_p, c_int, POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     L.ifl_rrdb_encode.restype = c_int
+    L.ifl_conv2d.argtypes = [POINTER(IflConvDesc), c_int, c_int, c_int, c_void_p]
+    L.ifl_conv2d.restype = c_int
+    L.ifl_conv2d_wgrad.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_void_p]
+    L.ifl_conv2d_wgrad.restype = c_int
     L.ifl_quantize_u8_nhwc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_quantize_u8_nhwc.restype = c_int
     L.ifl_set_schedule.argtypes = [c_int, c_int, c_int]
@@ -106,7 +119,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
-           "ifl_rrdb_ws_init", "ifl_rrdb_encode")
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
