@@ -242,6 +242,9 @@ class Gaussian:
 
     @staticmethod
     def logp(mean, cov, x):
+        if torch.is_grad_enabled() and (x.requires_grad or (cov is not None and (cov.requires_grad or mean.requires_grad))):
+            from . import train_flow
+            return train_flow.gaussian_logp(mean, cov, x)              # differentiable (training path)
         if mean is None and cov is None:
             return hip.gaussian_logp(x)
         # torch.inverse / torch.slogdet of the 48x48 covariance: tiny host-side linear algebra, as the reference

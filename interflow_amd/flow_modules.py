@@ -376,7 +376,24 @@ class FlowUpsamplerNet(nn.Module):
                                                  self._flags(), hip._stream()), "ifl_cond_prepare")
         return PreparedCond(rrdbResults, ws, ws.generation, (self._packed[0], self.conv_dtype), enc, (batch, H, W))
 
+    def _needs_autograd(self, src, rrdbResults):
+        """True when a gradient has to flow through this call: then the differentiable layer-by-layer path runs
+        (train_flow.py) instead of the fused inference kernels, which record nothing for autograd."""
+        if not torch.is_grad_enabled():
+            return False
+        if isinstance(src, torch.Tensor) and src.requires_grad:
+            return True
+        if any(isinstance(v, torch.Tensor) and v.requires_grad for v in rrdbResults.values()):
+            return True
+        return any(p.requires_grad for p in self.layers.parameters())
+
     def _run(self, src, rrdbResults, logdet, test_input_size, decode):
+        if self._needs_autograd(src, rrdbResults):
+            from . import train_flow
+            out, ld = train_flow.run(self, src, rrdbResults, logdet, test_input_size, decode)
+            if decode:
+                assert out.shape[1] == 3
+            return out, ld
         src = hip._dev_f32(src, "flow input")
         B = src.shape[0]
         if decode:

@@ -16,6 +16,14 @@ SCALES = [2, 4]
 RTOL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def _inference_only():
+    """These tests exercise the fused inference kernels: with autograd enabled and trainable parameters the modules would
+    take the differentiable training path instead (tests/test_gpu_train.py covers that one)."""
+    with torch.no_grad():
+        yield
+
+
 def dev():
     return torch.device("cuda:0")
 

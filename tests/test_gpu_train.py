@@ -50,3 +50,140 @@ def test_conv2d_ring_forward_and_gradients(cins, cout, k, B, h, w):
     assert rel(y2, yr - bias.reshape(1, -1, 1, 1)) < 1e-5
     y2.backward(gy.to(dev()))
     assert rel(wd2.grad, wr.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------- whole flow: values and gradients
+from interflow_amd import synth                                   # noqa: E402
+from interflow_amd.flow_model import InterpFlow                   # noqa: E402
+from oracle import interflow_oracle as O                          # noqa: E402
+
+SCALES = [2, 4]
+
+
+def _oracle_step(sd_np, x, feats, labels, add_noise_tensor=None):
+    """Loss and gradients of the training step's NLL + ib terms (train.py:73-75,110 with consistency_lambda = 0) by CPU
+    autograd over the oracle's restatement of the reference."""
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in sd_np.items()}
+    leaves = {k: v.requires_grad_() for k, v in sd.items()
+              if v.dtype == torch.float32 and (k.startswith("flow_upsampler.layers.") or k.startswith("mean_shift_") or k.startswith("cov_shift_"))
+              and not k.endswith(".p") and not k.endswith(".sign_s")}
+    fl = {k: v.clone().requires_grad_() for k, v in feats.items()}
+    B = x.shape[0]
+    z, ld = O.flow_encode(x, fl, sd, "flow_upsampler.", torch.zeros(B))
+    ms = [sd["mean_shift_0"], sd["mean_shift_1"]]
+    cs = [sd["cov_shift_0"], sd["cov_shift_1"]]
+    _, nll, _, ll_ib = O.calculate_loss(z, ld, x.shape[2] * x.shape[3], labels, SCALES, ms, cs)
+    loss = nll.mean() + 1.0 * (-ll_ib.mean())
+    loss.backward()
+    return z.detach(), ld.detach(), nll.detach(), ll_ib.detach(), loss.detach(), leaves, fl
+
+
+def test_training_step_values_and_gradients_vs_oracle():
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 2, 16
+    x = torch.from_numpy(synth.synth_images(81, B, H, H))
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(82, B, H, H).items()}
+    labels = torch.tensor([2, 4])
+    zr, ldr, nllr, ibr, lossr, leaves, fl = _oracle_step(sd_np, x, feats, labels)
+
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    fd = {k: v.to(dev()).requires_grad_() for k, v in feats.items()}
+    z, nll, ld, ll_ib = model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
+    assert rel(z, zr) < 1e-4 and rel(ld, ldr) < 1e-4 and rel(nll, nllr) < 1e-4 and rel(ll_ib, ibr) < 1e-3
+    loss = nll.mean() + 1.0 * (-ll_ib.mean())
+    assert rel(loss, lossr) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    worst = ("", 0.0)
+    checked = 0
+    for key, ref in leaves.items():
+        name = key.replace("flow_upsampler.", "arch.flowUpsamplerNet.") if key.startswith("flow_upsampler.") else key
+        p = named[name]
+        assert p.grad is not None, key
+        e = rel(p.grad, ref.grad)
+        worst = max(worst, (key, e), key=lambda t: t[1])
+        checked += 1
+    print(f"checked {checked} parameter gradients, worst {worst[0]}: {worst[1]:.2e}")
+    assert checked > 700 and worst[1] < 5e-4, worst
+    for k in ("fea_up2", "fea_up1"):
+        assert rel(fd[k].grad, fl[k].grad) < 5e-4, k
+    # the same module without autograd takes the fused kernels and gives the same values
+    model.eval()
+    with torch.no_grad():
+        z2, nll2, ld2, _ = model(x.to(dev()), None, labels.to(dev()), lr_enc={k: v.detach() for k, v in fd.items()}, add_gt_noise=False)
+    assert rel(z2, z) < 1e-4 and rel(ld2, ld) < 1e-4 and rel(nll2, nll) < 1e-4
+
+
+def test_decode_with_gradients_vs_oracle():
+    """The gradient-enabled decode (train.py:94, the LR-consistency branch) against CPU autograd of the oracle."""
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 1, 16
+    zin = torch.randn(B, 48, H // 4, H // 4, generator=torch.Generator().manual_seed(5))
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(83, B, H, H).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in sd_np.items()}
+    keys = [f"flow_upsampler.layers.{i}.{n}" for i, n in ((1, "actnorm.logs"), (3, "affine.fAffine.0.weight"), (20, "invconv.l"),
+                                                          (37, "affine.fFeatures.4.weight"), (37, "affine.fAffine.4.logs"))]
+    for k in keys:
+        sd[k].requires_grad_()
+    zr = zin.clone().requires_grad_()
+    xr, ldr = O.flow_decode(zr, feats, sd, "flow_upsampler.", torch.zeros(B), H)
+    (xr.square().mean() + 1e-3 * ldr.mean()).backward()
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    zd = zin.to(dev()).requires_grad_()
+    x, ld = model(zd, torch.zeros(B, 3, H, H, device=dev()), reverse=True, lr_enc={k: v.to(dev()) for k, v in feats.items()},
+                  add_gt_noise=False, test_input_size=H)
+    assert rel(x, xr) < 1e-4 and rel(ld, ldr) < 1e-4
+    (x.square().mean() + 1e-3 * ld.mean()).backward()
+    assert rel(zd.grad, zr.grad) < 5e-4
+    named = dict(model.named_parameters())
+    for k in keys:
+        assert rel(named[k.replace("flow_upsampler.", "arch.flowUpsamplerNet.")].grad, sd[k].grad) < 5e-4, k
+
+
+def test_data_dependent_actnorm_init():
+    """FlowActNorms.py:29-43: in training mode the first pass of a module whose bias is all zero sets bias/logs from the
+    batch so that its output has zero mean and unit variance per channel; initialised (loaded) modules are left alone."""
+    from interflow_amd import train_flow
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    zeroed = {k: (np.zeros_like(v) if ("actnorm.bias" in k or "actnorm.logs" in k) and k.startswith("arch.flowUpsamplerNet") else v)
+              for k, v in sd_np.items()}
+    for k in list(zeroed):          # aliases of the same tensors
+        if k.startswith("flow_upsampler.") and ("actnorm.bias" in k or "actnorm.logs" in k):
+            zeroed[k] = np.zeros_like(zeroed[k])
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in zeroed.items()}, strict=True)
+    model.train().to(dev())
+    B, H = 4, 16
+    x = torch.from_numpy(synth.synth_images(84, B, H, H)).to(dev())
+    feats = {k: torch.from_numpy(v).to(dev()) for k, v in synth.synth_features(85, B, H, H).items()}
+    seen = []
+    real = train_flow.actnorm
+
+    def spy(an, x_cl, logdet=None, reverse=False):
+        first = not an.inited
+        out = real(an, x_cl, logdet, reverse)
+        if first:
+            seen.append((out[0].detach().mean(dim=(0, 1, 2)).abs().max().item(),
+                         (out[0].detach() ** 2).mean(dim=(0, 1, 2)).sub(1).abs().max().item()))
+        return out
+    train_flow.actnorm = spy
+    try:
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    finally:
+        train_flow.actnorm = real
+    assert len(seen) == 36 + 32 * 4, len(seen)          # 36 flow-level ActNorms + 2 per coupling network
+    assert max(m for m, _ in seen) < 1e-4 and max(v for _, v in seen) < 1e-3, (max(m for m, _ in seen), max(v for _, v in seen))
+    assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+    assert all(m.inited for m in model.modules() if type(m).__name__ == "ActNorm2d" and m in set(model.flow_upsampler.modules()))
+    before = {k: v.clone() for k, v in model.state_dict().items() if "actnorm" in k}
+    model(x * 0.5, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)          # second pass: no re-initialisation
+    assert all(torch.equal(v, model.state_dict()[k]) for k, v in before.items())
+    # eval mode never initialises; the fused inference path then sees the initialised parameters
+    model.eval()
+    with torch.no_grad():
+        z2, ld2 = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    assert rel(z2, z) < 1e-4 and rel(ld2, ld) < 1e-4
