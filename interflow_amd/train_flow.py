@@ -75,7 +75,8 @@ def invconv_weight(ic, reverse):
     else:
         l = torch.inverse(l.double()).float()
         u = torch.inverse(u.double()).float()
-        w = torch.matmul(u, torch.matmul(l, ic.p.inverse()))
+        w = torch.matmul(u, torch.matmul(l, ic.p.t()))      # p is a permutation matrix: p.inverse() == p^T exactly
+        # (torch.linalg.inv of a permutation matrix fails on this ROCm build: its LU runs without pivoting)
     return w, dl
 
 
