@@ -187,3 +187,31 @@ def test_data_dependent_actnorm_init():
     with torch.no_grad():
         z2, ld2 = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
     assert rel(z2, z) < 1e-4 and rel(ld2, ld) < 1e-4
+
+
+def test_train_step_harness_learns():
+    """interflow_amd.training.train_step (train.py:66-131, NLL + ib): a few Adam iterations on one fixed batch lower the
+    loss, parameters of the flow, the prior and the encoder all move, dead parameters do not."""
+    from interflow_amd import training
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    opt, sched = training.make_optimizer(model, lr=1e-4)                 # train.py's learning rate
+    red = training.GradientAllReducer(model.parameters(), None)
+    B, H = 2, 32
+    gt = torch.from_numpy(synth.synth_images(91, B, H, H)).to(dev())
+    lr = torch.from_numpy(synth.synth_images(92, B, H, H)).to(dev())
+    labels = torch.tensor([2, 4], device=dev())
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    losses = []
+    for it in range(4):
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, step=it, add_gt_noise=False)
+        assert not out["skipped"] and np.isfinite(out["loss"]), (it, out, losses)
+        losses.append(out["loss"])
+    print("losses", losses)
+    assert losses[-1] < losses[0]
+    moved = {k: not torch.equal(v, before[k]) for k, v in model.named_parameters()}
+    assert moved["arch.flowUpsamplerNet.layers.3.affine.fAffine.0.weight"] and moved["mean_shift_0"] and moved["cov_shift_1"]
+    assert moved["arch.RRDB.RRDB_trunk.0.RDB1.conv1.weight"] and moved["arch.flowUpsamplerNet.layers.1.invconv.l"]
+    assert not moved["degradation_net.net.0.weight"] and not moved["arch.RRDB.conv_last.weight"]

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[3]: flow training step (NLL + ib, forward + backward + Adam), batch 8 per GPU (global 64 on 8
+GPUs), 160x160 patches, fp32; one process per GPU, gradient all-reduce over RCCL (interflow_amd.training).
+
+  python tools/bench_train.py [--steps 5] [--warmup 2] [--batch 8] [--frozen-rrdb]
+  torchrun --nproc-per-node N tools/bench_train.py ...
+
+Prints one JSON line: training patches/s (whole job), ms per step, and the split of one step measured with
+torch.cuda.synchronize() between phases on rank 0 (encoder, flow forward, backward incl. all-reduce, optimizer)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from interflow_amd import shard, synth, training  # noqa: E402
+from interflow_amd.flow_model import InterpFlow  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--patch", type=int, default=160)
+    ap.add_argument("--frozen-rrdb", action="store_true", help="do not train the conditioning encoder (no gradient wrt ft)")
+    args = ap.parse_args()
+    rank, local_rank, world = shard.dist_env()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = shard.init_dist("nccl", dev)
+    model = InterpFlow([2, 4])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_interpflow_state([2, 4], seed=0).items()})
+    model.train().to(dev)
+    if args.frozen_rrdb:
+        model.arch.set_rrdb_training(False)
+    training.broadcast_parameters(model, dist)
+    opt, sched = training.make_optimizer(model, lr=1e-4)
+    red = training.GradientAllReducer(model.parameters(), dist)
+    B, P = args.batch, args.patch
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    gt = torch.rand(B, 3, P, P, device=dev, generator=g)
+    lr = torch.rand(B, 3, P, P, device=dev, generator=g)
+    labels = torch.tensor([2, 4] * (B // 2) + [2] * (B % 2), device=dev)
+    for _ in range(args.warmup):
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched)
+    shard.barrier(dist, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched)
+    shard.barrier(dist, dev)
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dist, dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        return time.perf_counter()
+    t = [sync()]
+    lr_enc = model.arch.rrdbPreprocessing(gt); t.append(sync())
+    z, nll, ld, ll_ib = model(lr, gt, labels, lr_enc=lr_enc); t.append(sync())
+    loss = nll.mean() - ll_ib.mean()
+    red.zero_grad(); loss.backward(); red.finish(); t.append(sync())
+    opt.step(); t.append(sync())
+    if rank == 0:
+        print(json.dumps({"workload": f"training step (NLL + ib; forward, backward, Adam), batch {B} of {P}x{P} per GPU, fp32, "
+                                      f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained (PyTorch-ROCm autograd)'}",
+                          "n_gpus": world, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                          "patches_per_s": B * world * args.steps / dt, "last": out,
+                          "split_ms": {"encoder_fwd": (t[1] - t[0]) * 1e3, "flow_fwd_loss": (t[2] - t[1]) * 1e3,
+                                       "backward_allreduce": (t[3] - t[2]) * 1e3, "adam": (t[4] - t[3]) * 1e3}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
