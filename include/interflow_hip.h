@@ -161,8 +161,8 @@ int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb,
  * of flow.py:27 / nn.Conv2d(padding=1)); a source or destination is a channel range [off, off+n) of such a buffer.
  * ifl_conv2d: out = epilogue(conv(cat(src0, src1), w) + bias), stride 1, 3x3 (taps 9) or 1x1 (taps 1).  Channel counts are
  * multiples of 32 (pad with zero channels / zero weights).  w is in fragment order: element
- *   [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][half h][i][e] = W[out = group*32*MT + mt*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap]
- * with MT = 2 when cout % 64 == 0, else 1.  Epilogue: act (0 none, 1 LeakyReLU 0.2, 2 ReLU), then v = v*alpha + res1,
+ *   [group of 32 outputs][chunk of 32 inputs][tap][kq][half h][i][e] = W[out = group*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap].
+ * Epilogue: act (0 none, 1 LeakyReLU 0.2, 2 ReLU), then v = v*alpha + res1,
  * then v = v*beta + res2 (each optional).  Only interior pixels are written.
  * The data gradient of a convolution is ifl_conv2d with the transposed, spatially flipped weights.
  * ifl_conv2d_wgrad: dW[co][ci0*32 + ci][tap] += sum_{b,px} dy[b,px][co] * x[b,px+tap][ci] for the cin channels of one

@@ -65,7 +65,9 @@ void convg_kernel(IflConvArgs a)
 
     const int nchunks = a.nchunks;
     constexpr int KQ = 4;                                         // k-steps of 8 channels per 32-channel chunk
-    const float* wl = a.w + (int64_t)grp * nchunks * (TAPS * KQ * MT * 256) + lane * 4;
+    // weights: one record per 32 output channels, [chunk][tap][kq][64 lanes x 4]; this workgroup reads records grp*MT .. +MT
+    const int64_t wrec = (int64_t)nchunks * (TAPS * KQ * 256);
+    const float* wl = a.w + (int64_t)grp * MT * wrec + lane * 4;
 
     auto chunk_src = [&](int cc, int i) -> const float* {         // source pointer of staging slot i for chunk cc
         int s = 0, c = cc;
@@ -89,11 +91,11 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
             for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(cc + 1, i);
         }
-        const float* wc = wl + (int64_t)cc * (TAPS * KQ * MT * 256);
+        const float* wc = wl + (int64_t)cc * (TAPS * KQ * 256);
         constexpr int ITERS = TAPS * KQ;
         f32x4 wq[2][MT], xb[2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wq[0][m] = *(const f32x4*)(wc + m * 256);
+        for (int m = 0; m < MT; ++m) wq[0][m] = *(const f32x4*)(wc + m * wrec);
         xb[0] = *(const f32x4*)((const char*)lds + a0);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -102,7 +104,7 @@ void convg_kernel(IflConvArgs a)
                 const int tapoff = TAPS == 9 ? ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4) : 0;
                 xb[(it + 1) & 1] = *(const f32x4*)((const char*)lds + a0 + tapoff + kq * 32);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + ((it + 1) * MT + m) * 256);
+                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + m * wrec + (it + 1) * 256);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -153,7 +155,8 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
     IFL_CHECK_ARG(a.cout % 32 == 0 && a.cout > 0, IFL_EINVAL, "convg: Cout=%d is not a multiple of 32", a.cout);
     IFL_CHECK_ARG(a.taps == 9 || a.taps == 1, IFL_EINVAL, "convg: taps=%d", a.taps);
     IFL_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2 && a.nchunks >= 1, IFL_EINVAL, "convg: sources");
-    const int mt = (a.cout % 64 == 0) ? 2 : 1;
+    // 64 output channels per workgroup when that still fills the chip, else 32 (twice the workgroups, half the latency each)
+    const int mt = (a.cout % 64 == 0 && (int64_t)a.g.ntiles * B * (a.cout / 64) >= 256) ? 2 : 1;
     dim3 grid(a.g.ntiles, B, a.cout / (32 * mt)), block(256);
     if (mt == 2 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<2, 9>), grid, block, 0, st, a);
     else if (mt == 1 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9>), grid, block, 0, st, a);

@@ -122,8 +122,8 @@ struct IflWs {
 // Input channels = up to two sources read one after the other (each a channel range, a multiple of 32 wide, of a ringed
 // channels-last buffer); output = `cout` channels (multiple of 32) written at channel out_off of a ringed buffer.
 //   v = conv + bias;  act (1 LeakyReLU 0.2, 2 ReLU);  if res1: v = v*alpha + res1;  if res2: v = v*beta + res2.
-// Weights: [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][lane half h][lane i][e] =
-//          W[out = group*32*MT + mt*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap]   (MT = 2 when cout % 64 == 0, else 1).
+// Weights: [group of 32 outputs][chunk of 32 inputs][tap][kq][lane half h][lane i][e] =
+//          W[out = group*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap].
 struct IflConvArgs {
     const float* src[2]; int src_stride[2], src_off[2], src_chunks[2]; int nsrc, nchunks;
     const float* w; const float* bias;

@@ -80,7 +80,57 @@ class RRDBNet(nn.Module):
         n, c, h, w = x.size()                                                         # :79-83
         return F.unfold(x, block_size, stride=block_size).view(n, c * block_size ** 2, h // block_size, w // block_size)
 
+    def _forward_hipconv(self, x, get_steps):
+        """The same forward with every nn.Conv2d evaluated by the differentiable HIP convolution (train_ops.conv2d_ring:
+        forward, data gradient and weight gradient on the library's kernels) on ringed channels-last tensors; the
+        activations, residuals, concatenations and resizes are ATen glue.  Used when autograd must reach the encoder."""
+        from . import train_ops as T
+
+        def conv(m, t, cin):
+            return T.conv2d_ring([t], [cin], m.weight, m.bias)
+
+        def lrelu(t):
+            return F.leaky_relu(t, 0.2)
+
+        def rdb(m, t):                                                            # RRDBNet_arch.py:23-29
+            x1 = lrelu(conv(m.conv1, t, 64))
+            x2 = lrelu(conv(m.conv2, torch.cat((t, x1), -1), 96))
+            x3 = lrelu(conv(m.conv3, torch.cat((t, x1, x2), -1), 128))
+            x4 = lrelu(conv(m.conv4, torch.cat((t, x1, x2, x3), -1), 160))
+            x5 = conv(m.conv5, torch.cat((t, x1, x2, x3, x4), -1), 192)
+            return x5 * 0.2 + t
+
+        def up2(t):                                                               # nearest x2 of a ringed tensor
+            i = t[:, 1:-1, 1:-1, :]
+            return T.ring_of(i.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2))
+
+        nf = self.conv_first.weight.shape[0]
+        fea = conv(self.conv_first, T.to_ring(self.space2depth(x, 4)), self.conv_first.weight.shape[1])
+        block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []
+        block_results = {}
+        for idx, m in enumerate(self.RRDB_trunk.children()):
+            fea = rdb(m.RDB3, rdb(m.RDB2, rdb(m.RDB1, fea))) * 0.2 + fea            # :41-45
+            if idx in block_idxs:
+                block_results["block_{}".format(idx)] = T.from_ring(fea, nf)
+        last = fea + conv(self.trunk_conv, fea, nf)
+        f2 = lrelu(conv(self.upconv1, up2(last), nf))
+        f4 = lrelu(conv(self.upconv2, up2(f2), nf))
+        out = T.from_ring(conv(self.conv_last, lrelu(conv(self.HRconv, f4, nf)), nf), self.conv_last.weight.shape[0])
+        last_lr_fea, fea_up2, fea_up4 = T.from_ring(last, nf), T.from_ring(f2, nf), T.from_ring(f4, nf)
+        results = {'last_lr_fea': last_lr_fea, 'fea_up1': last_lr_fea, 'fea_up2': fea_up2, 'fea_up4': fea_up4,
+                   'fea_up8': None, 'fea_up16': None, 'fea_up32': None, 'out': out}
+        if opt_get(self.opt, ['network_G', 'flow', 'fea_up0']) or False:
+            results['fea_up0'] = F.interpolate(last_lr_fea, scale_factor=1 / 2, mode='bilinear')
+        if opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False:
+            results['fea_up-1'] = F.interpolate(last_lr_fea, scale_factor=1 / 4, mode='bilinear')
+        if get_steps:
+            results.update(block_results)
+            return results
+        return out
+
     def forward(self, x, get_steps=False):
+        if x.is_cuda and x.dtype == torch.float32:
+            return self._forward_hipconv(x, get_steps)
         x = self.space2depth(x, 4)
         fea = self.conv_first(x)
         block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []

@@ -203,15 +203,13 @@ def pack_flow(prm, kinds, pfx="", training=False):
 # ------------------------------------------------------------------------------------- conditioning encoder
 def pack_conv_generic(w, cin_pad, cout_pad):
     """nn.Conv2d weight [Cout, Cin, kh, kw] -> convg.hip fragment order
-    [group of 32*MT outputs][chunk of 32 inputs][tap][kq][mt][h][i][e], zero-padded to (cout_pad, cin_pad)."""
+    [group of 32 outputs][chunk of 32 inputs][tap][kq][h][i][e], zero-padded to (cout_pad, cin_pad)."""
     cout, cin, kh, kw = w.shape
     taps = kh * kw
     wp = np.zeros((cout_pad, cin_pad, taps), F32)
     wp[:cout, :cin] = w.reshape(cout, cin, taps)
-    mt = 2 if cout_pad % 64 == 0 else 1
-    g = cout_pad // (32 * mt)
-    wp = wp.reshape(g, mt, 32, cin_pad // 32, 4, 2, 4, taps)          # g mt i chunk kq h e tap
-    return np.ascontiguousarray(wp.transpose(0, 3, 7, 4, 1, 5, 2, 6)).reshape(-1)
+    wp = wp.reshape(cout_pad // 32, 32, cin_pad // 32, 4, 2, 4, taps)  # g i chunk kq h e tap
+    return np.ascontiguousarray(wp.transpose(0, 2, 6, 3, 4, 1, 5)).reshape(-1)
 
 
 def rrdb_conv_names(nb):

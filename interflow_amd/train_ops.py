@@ -42,9 +42,7 @@ def ring_of(interior: torch.Tensor) -> torch.Tensor:
 def pack_weight(wp: torch.Tensor) -> torch.Tensor:
     """[cout_pad, cin_pad, taps] -> fragment order of ifl_conv2d (see interflow_hip.h), on the tensor's device."""
     cout, cin, taps = wp.shape
-    mt = 2 if cout % 64 == 0 else 1
-    g = cout // (32 * mt)
-    return wp.reshape(g, mt, 32, cin // 32, 4, 2, 4, taps).permute(0, 3, 7, 4, 1, 5, 2, 6).contiguous()
+    return wp.reshape(cout // 32, 32, cin // 32, 4, 2, 4, taps).permute(0, 2, 6, 3, 4, 1, 5).contiguous()
 
 
 def _padded_weight(weight: torch.Tensor, splits, cout_pad: int) -> torch.Tensor:

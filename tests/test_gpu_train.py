@@ -215,3 +215,34 @@ def test_train_step_harness_learns():
     assert moved["arch.flowUpsamplerNet.layers.3.affine.fAffine.0.weight"] and moved["mean_shift_0"] and moved["cov_shift_1"]
     assert moved["arch.RRDB.RRDB_trunk.0.RDB1.conv1.weight"] and moved["arch.flowUpsamplerNet.layers.1.invconv.l"]
     assert not moved["degradation_net.net.0.weight"] and not moved["arch.RRDB.conv_last.weight"]
+
+
+def test_encoder_gradients_vs_oracle():
+    """The conditioning encoder with autograd (RRDBNet on the differentiable HIP convolution): values of every key and
+    the gradients of all its parameters against CPU autograd of the oracle."""
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H, W = 2, 16, 24
+    x = torch.from_numpy(synth.synth_images(93, B, H, W))
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in sd_np.items()}
+    leaves = {k: v.requires_grad_() for k, v in sd.items() if k.startswith("arch.RRDB.")}
+    want = O.rrdb_preprocessing(x, sd, "arch.RRDB.")
+    g = torch.Generator().manual_seed(4)
+    probes = {k: torch.randn(want[k].shape, generator=g) for k in ("fea_up1", "fea_up2", "fea_up4", "fea_up0", "out")}
+    sum((want[k] * probes[k]).sum() for k in probes).backward()
+
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    got = model.arch.rrdbPreprocessing(x.to(dev()))
+    for k in probes:
+        assert rel(got[k], want[k]) < 1e-4, k
+    sum((got[k] * probes[k].to(dev())).sum() for k in probes).backward()
+    named = dict(model.named_parameters())
+    worst, n = ("", 0.0), 0
+    for k, ref in leaves.items():
+        p = named[k]
+        assert p.grad is not None, k
+        worst = max(worst, (k, rel(p.grad, ref.grad)), key=lambda t: t[1])
+        n += 1
+    print(f"checked {n} encoder gradients, worst {worst[0]}: {worst[1]:.2e}")
+    assert n == 2 * (23 * 15 + 6) and worst[1] < 5e-4, worst
