@@ -10,8 +10,9 @@ iteration is the gradient all-reduce (RCCL over xGMI on GPUs, gloo in the CPU te
   simply stay zero in their bucket.
 * `broadcast_parameters` -- after the data-dependent ActNorm initialisation (FlowActNorms.py:29-43) of rank 0's first
   batch, so that all replicas start identical.
-* `train_step` -- `train.py:72-75,110-131` with `consistency_lambda = 0` (the LR-consistency branch needs the bicubic
-  resize of utils/resize_right.py, SURVEY.md section 8(f) row 3, not built).
+* `train_step` -- `train.py:72-131`: NLL + ib terms and, when a pair of differently scaled LR images is given, the
+  LR-consistency term (two more encodes, latent blend, gradient-enabled decode, antialiased bicubic x1/4 of
+  `interflow_amd/resize.py`, L1).
 """
 from __future__ import annotations
 
@@ -126,17 +127,48 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-4):
     return opt, sched
 
 
+def consistency_loss(model, gt, lr_enc, low_res, img_lr1, scale1, img_lr2, scale2, interpolate_weight=None,
+                     add_gt_noise: bool = True):
+    """The LR-consistency term, train.py:78-106: blend the latents of two differently scaled LR images with per-sample
+    weights, decode, and compare (L1) the x1/4 antialiased-bicubic reductions of the decoded image and of the blended
+    LR images.  interpolate_weight: per-sample weights in [0, 1] (drawn as train.py:81,88 does when None)."""
+    from .resize import resize_last2
+    B = gt.shape[0]
+    if interpolate_weight is None:
+        target = torch.distributions.Uniform(float(scale1), float(scale2)).sample([B]).to(gt.device)      # :81
+        interpolate_weight = (target - scale1) / (scale2 - scale1)                                        # :88
+    z1, _ = model(img_lr1, gt, torch.tensor([scale1] * B), lr_enc=lr_enc, calc_loss=False, add_gt_noise=add_gt_noise)   # :85
+    z2, _ = model(img_lr2, gt, torch.tensor([scale2] * B), lr_enc=lr_enc, calc_loss=False, add_gt_noise=add_gt_noise)   # :86
+    w1 = (1 - interpolate_weight).reshape(-1, 1, 1, 1)                                  # :89
+    w2 = interpolate_weight.reshape(-1, 1, 1, 1)                                        # :90
+    interpolated_z = w1 * z1 + w2 * z2                                                  # :92
+    interpolated_img, _ = model(interpolated_z, gt, reverse=True, test_input_size=low_res.shape[2], lr_enc=lr_enc,
+                                add_gt_noise=add_gt_noise)                              # :94
+    synth_lr = torch.zeros_like(low_res) + w1 * img_lr1 + w2 * img_lr2                  # :99-100
+    synth_lr = synth_lr + ((torch.rand(synth_lr.shape, device=synth_lr.device) - 0.5) / 256)     # :101
+    interp_down = resize_last2(interpolated_img, 1. / 4)                                # :102
+    synth_down = resize_last2(synth_lr, 1. / 4)                                         # :103
+    return torch.nn.functional.l1_loss(synth_down, interp_down).mean()                  # :104-106
+
+
 def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, reducer: Optional[GradientAllReducer] = None,
-               scheduler=None, step: int = 0, add_gt_noise: bool = True):
-    """One iteration of train.py:66-131 with consistency_lambda = 0.  Returns a dict of python floats (this synchronises,
-    as the reference's progress bar does at train.py:133-134) and `skipped`."""
+               scheduler=None, step: int = 0, add_gt_noise: bool = True, consistency_lambda: float = 0.0, interp=None,
+               interpolate_weight=None):
+    """One iteration of train.py:66-131.  interp = (img_lr1, scale1, img_lr2, scale2) enables the LR-consistency term
+    (weight consistency_lambda; train.py's default is 10).  Returns a dict of python floats (this synchronises, as the
+    reference's progress bar does at train.py:133-134) and `skipped`."""
     lr_enc = model.arch.rrdbPreprocessing(gt)                                           # train.py:72
     z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc, add_gt_noise=add_gt_noise)     # :73
     ib_loss = -torch.mean(ll_ib)                                                        # :74
     nll_loss = torch.mean(nll)                                                          # :75
-    loss = nll_loss + ib_lambda * ib_loss                                               # :110
+    if consistency_lambda > 0 and interp is not None:                                   # :78-106
+        cons = consistency_loss(model, gt, lr_enc, low_res, *interp, interpolate_weight=interpolate_weight,
+                                add_gt_noise=add_gt_noise)
+    else:
+        cons = torch.zeros((), device=gt.device)                                        # :107-108
+    loss = nll_loss + consistency_lambda * cons + ib_lambda * ib_loss                   # :110
     out = {"skipped": False}
-    bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss) > 30)         # :113-126
+    bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss.detach()) > 30)         # :113-126
     if bad:
         out["skipped"] = True
         if reducer is not None:
@@ -156,5 +188,6 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
         optimizer.step()                                                                # :130
         if scheduler is not None:
             scheduler.step()                                                            # :131
-    out.update(loss=float(loss), nll=float(nll_loss), ib_loss=float(ib_loss))
+    out.update(loss=float(loss.detach()), nll=float(nll_loss.detach()), ib_loss=float(ib_loss.detach()),
+               consistency_loss=float(cons.detach()))
     return out

@@ -446,3 +446,43 @@ def weighted_interpolate(sd, lr1, lr2, a, lr_enc):
 
 def to_torch(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+
+
+# ----------------------------------------------------------------------------- ResizeRight (LR-consistency loss)
+def _cubic(x):
+    """utils/interp_methods.py:35-43"""
+    absx = torch.abs(x)
+    absx2, absx3 = absx ** 2, absx ** 3
+    return ((1.5 * absx3 - 2.5 * absx2 + 1.) * (absx <= 1.).to(x.dtype) +
+            (-0.5 * absx3 + 2.5 * absx2 - 4. * absx + 2.) * ((1. < absx) & (absx <= 2.)).to(x.dtype))
+
+
+def resize_right(x, scale):
+    """utils/resize_right.py:32-123 for resize(x, scale_factors=scale, interp_method=cubic, antialiasing=True): last two
+    dims, gather formulation as the reference (field of view, zero 'constant' padding, weights normalised per output)."""
+    eps = torch.finfo(torch.float32).eps
+    out = x
+    for dim in (x.ndim - 2, x.ndim - 1):
+        in_sz = x.shape[dim]
+        out_sz = math.ceil(scale * in_sz)                                                    # :302-304
+        grid = torch.arange(out_sz) / float(scale) + (in_sz - 1) / 2 - (out_sz - 1) / (2 * float(scale))   # :126-137
+        if scale < 1.0:                                                                      # :343-355
+            interp, sup = (lambda a: scale * _cubic(scale * a)), 4 / scale
+        else:
+            interp, sup = _cubic, 4.0
+        left = (grid - sup / 2 - eps).ceil().long()                                          # :140-149
+        fov = left[:, None] + torch.arange(math.ceil(sup - eps))
+        pad = [-fov[0, 0].item(), fov[-1, -1].item() - in_sz + 1]                            # :152-164
+        fov, grid = fov + pad[0], grid + pad[0]
+        w = interp(grid[:, None] - fov)                                                      # :201-212
+        s = w.sum(1, keepdim=True)
+        s[s == 0] = 1
+        w = w / s
+        t = out.transpose(dim, 0)                                                            # :215-247
+        if pad[0] > 0 or pad[1] > 0:
+            t = F.pad(t.transpose(0, -1), (max(pad[0], 0), max(pad[1], 0))).transpose(0, -1)
+        if pad[0] < 0 or pad[1] < 0:                                                         # negative pad = crop
+            t = t[(-pad[0] if pad[0] < 0 else 0):(t.shape[0] + pad[1] if pad[1] < 0 else t.shape[0])]
+        nb = t[fov]
+        out = (nb * w.reshape(*w.shape, *[1] * (x.ndim - 1))).sum(1).transpose(0, dim)
+    return out

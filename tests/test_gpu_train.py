@@ -246,3 +246,51 @@ def test_encoder_gradients_vs_oracle():
         n += 1
     print(f"checked {n} encoder gradients, worst {worst[0]}: {worst[1]:.2e}")
     assert n == 2 * (23 * 15 + 6) and worst[1] < 5e-4, worst
+
+
+def test_full_training_step_against_reference_golden(golden_dir):
+    """The whole default training step of the reference -- NLL + ib + 10 x LR-consistency (train.py:72-110), random draws
+    pinned -- against outputs and gradients of the reference itself (tests/golden/train_seed0.npz): loss terms, the
+    decoded interpolated image, eight gradient tensors in full and sum / sum-of-squares checksums of all 1456 gradients."""
+    import os
+    from interflow_amd import training
+    g = np.load(os.path.join(golden_dir, "train_seed0.npz"))
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    assert str(g["digest"]) == synth.state_digest(sd_np)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    B, H = 2, 32
+    gt, low_res, lr1, lr2 = (torch.from_numpy(synth.synth_images(s, B, H, H)).to(dev()) for s in (201, 202, 203, 204))
+    labels = torch.tensor([2, 4], device=dev())
+    w = torch.from_numpy(g["w"]).to(dev())
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.full(a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a, 0.5,
+                                            device=k.get("device"))                  # zero noise, as in the fixture
+    try:
+        lr_enc = model.arch.rrdbPreprocessing(gt)
+        z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc)
+        cons = training.consistency_loss(model, gt, lr_enc, low_res, lr1, 2, lr2, 4, interpolate_weight=w)
+    finally:
+        torch.rand = real_rand
+    loss = nll.mean() + 10 * cons + 1 * (-ll_ib.mean())
+    assert rel(nll, torch.from_numpy(g["nll"])) < 1e-4 and rel(ll_ib, torch.from_numpy(g["ll_ib"])) < 1e-3
+    assert rel(cons, torch.from_numpy(g["cons"])) < 1e-3 and rel(loss, torch.from_numpy(g["loss"])) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("g_"):
+            name = k[2:].replace("flow_upsampler.", "arch.flowUpsamplerNet.")
+            assert rel(named[name].grad, torch.from_numpy(g[k])) < 1e-3, k
+    worst = 0.0
+    for name, s_ref, q_ref in zip(g["grad_names"], g["grad_sum"], g["grad_sq"]):
+        gr = named[str(name)].grad
+        assert gr is not None, name
+        q = float((gr.double() ** 2).sum())
+        s = float(gr.double().sum())
+        assert abs(q - q_ref) <= 2e-3 * q_ref + 1e-30, (name, q, q_ref)
+        assert abs(s - s_ref) <= 2e-3 * np.sqrt(q_ref * gr.numel()) + 1e-30, (name, s, s_ref)
+        worst = max(worst, abs(q - q_ref) / (q_ref + 1e-30))
+    got_names = {n for n, p in named.items() if p.grad is not None}
+    assert got_names == set(str(n) for n in g["grad_names"])
+    print(f"1456 gradient checksums, worst relative sum-of-squares error {worst:.2e}")
