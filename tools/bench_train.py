@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--patch", type=int, default=160)
+    ap.add_argument("--consistency", action="store_true", help="add the LR-consistency term (train.py's default lambda 10)")
     ap.add_argument("--frozen-rrdb", action="store_true", help="do not train the conditioning encoder (no gradient wrt ft)")
     args = ap.parse_args()
     rank, local_rank, world = shard.dist_env()
@@ -46,12 +47,16 @@ def main():
     gt = torch.rand(B, 3, P, P, device=dev, generator=g)
     lr = torch.rand(B, 3, P, P, device=dev, generator=g)
     labels = torch.tensor([2, 4] * (B // 2) + [2] * (B % 2), device=dev)
+    kw = {}
+    if args.consistency:
+        kw = dict(consistency_lambda=10.0, interp=(torch.rand(B, 3, P, P, device=dev, generator=g), 2,
+                                                   torch.rand(B, 3, P, P, device=dev, generator=g), 4))
     for _ in range(args.warmup):
-        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched)
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, **kw)
     shard.barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched)
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, **kw)
     shard.barrier(dist, dev)
     dt = shard.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
@@ -66,7 +71,7 @@ def main():
     opt.step(); t.append(sync())
     if rank == 0:
         print(json.dumps({"workload": f"training step (NLL + ib; forward, backward, Adam), batch {B} of {P}x{P} per GPU, fp32, "
-                                      f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained (PyTorch-ROCm autograd)'}",
+                                      f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained'}{', with LR-consistency term' if args.consistency else ''}",
                           "n_gpus": world, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                           "patches_per_s": B * world * args.steps / dt, "last": out,
                           "split_ms": {"encoder_fwd": (t[1] - t[0]) * 1e3, "flow_fwd_loss": (t[2] - t[1]) * 1e3,
