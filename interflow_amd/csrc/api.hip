@@ -88,6 +88,8 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
         case IFL_F_W1A_BF16: return o.w1b[0];
         case IFL_F_W1F_BF16: return o.w1b[1];
         case IFL_F_W2F_BF16: return o.w2b;
+        case IFL_F_W1A_WINO: return o.w1w[0];
+        case IFL_F_W1F_WINO: return o.w1w[1];
     }
     return -1;
 }
@@ -315,6 +317,21 @@ Sched& sched()
     return s;
 }
 
+// algorithm of the bulk kernel (fp32): 1 = Winograd F(2x2,3x3) (default), 0 = direct implicit GEMM
+int& conv1_algo()
+{
+    static int a = env_int("IFL_CONV1_WINO", 1) ? 1 : 0;
+    return a;
+}
+
+int conv1_ft(const IflLevelWs& lv, float* h2, const float* params, const IflStepList& steps, int nsteps, const IflStepOff& off,
+             int B, int level, int bf16, hipStream_t st)
+{
+    if (!bf16 && conv1_algo() == 1)
+        return ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, B, lv.H, lv.W, level, st);
+    return ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, B, level, bf16, st);
+}
+
 int n_groups(int B)
 {
     int g = sched().groups;
@@ -371,7 +388,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
         for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
         int rc;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2 + (int64_t)s0 * lv.h2_step, lv.h2_step, params, sub, s1 - s0, off, lv.geom, w.B, lvl + 1, bf16, st); }
+          rc = conv1_ft(lv, lv.h2 + (int64_t)s0 * lv.h2_step, params, sub, s1 - s0, off, w.B, lvl + 1, bf16, st); }
         if (rc) return rc;
         if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
     }
@@ -482,6 +499,13 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
 }
 }  // namespace
 
+extern "C" int ifl_set_conv1_algo(int algo)
+{
+    int prev = conv1_algo();
+    if (algo == 0 || algo == 1) conv1_algo() = algo;
+    return prev;
+}
+
 extern "C" int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps)
 {
     IFL_CHECK_ARG(groups <= IFL_MAX_GROUPS && p1_chunk_steps <= IFL_MAX_COND, IFL_EINVAL,
@@ -570,7 +594,7 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
         IflStepList one{};
         one.off[0] = layer->param_off;
         { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = ifl_k_conv1_ft(lv.ft, lv.h2, lv.h2_step, params, one, 1, ifl_step_off(lv.C, 1), lv.geom, B, lvl + 1, 0, st); }
+          rc = conv1_ft(lv, lv.h2, params, one, 1, ifl_step_off(lv.C, 1), B, lvl + 1, 0, st); }
         if (rc) return rc;
     }
     rc = reverse ? step_decode(*layer, params, w, lv, lv.h2, slots, constant, eps, st)

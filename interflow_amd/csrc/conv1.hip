@@ -250,6 +250,224 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
 }
 
 
+// ---- phase 1, Winograd F(2x2, 3x3) form -----------------------------------------------------------------------------------
+// The same sums as conv1_ft_kernel with 2.25x fewer multiplications (Lavin & Gray's minimal filtering, fp32 throughout):
+//   Y = A^T [ sum_ci U[co][ci] (.) V[ci] ] A,   U = G g G^T (host, float64 -> fp32, pack.py),   V = B^T d B
+// for every 2x2 output tile and its 4x4 input window d.  For each of the 16 positions f = (i, jc) of the transformed
+// domain the sum over input channels is a GEMM  M_f[co][tile] = U_f[co][ci] V_f[ci][tile]  on the fp32 matrix cores.
+//
+// Workgroup = 32 consecutive tiles (raster order over image, tile row, tile column) = 128 output pixels, 8 waves =
+// 2 networks x 4 columns jc of the transformed domain; a wave accumulates its 4 positions (i = 0..3, jc) x 64 output
+// channels x 32 tiles = 128 accumulator registers.  Per 32-channel chunk:
+//   * every thread loads the 3 x 4 window pixels it needs for (tile, channel quad, upper/lower half of i) straight from
+//     global memory (the neighbours' windows overlap; the overlap is served by the L1), transforms them in registers and
+//     writes V[f][tile][ch] to LDS (double-buffered: the loads and the transform of chunk c+1 overlap the GEMM of chunk c,
+//     one barrier per chunk);
+//   * the GEMM reads V as the B operand (one 16-byte LDS read per 8 MFMAs); weights stream global -> VGPR through a ring.
+// Epilogue: A^T along i is local to a wave; A along jc goes through LDS between the four waves of a network, after which
+// wave jc holds the pixels (dy, dx) = (jc >> 1, jc & 1) of the 32 tiles in the usual accumulator layout, so the ActNorm /
+// ReLU / 1x1 / store code of the direct kernel is shared.
+constexpr int WV_TS = 36;                     // words per (position, tile) row of V: 32 channels + 4 (conflict-free b128 reads)
+constexpr int WV_BUF = 16 * 32 * WV_TS;       // floats per V buffer (73,728 B)
+
+template <int LVL>
+__global__ __launch_bounds__(512, 1)
+void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
+                          const float* __restrict__ params, IflStepList steps, IflStepOff off, IflWGeom g)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * WV_BUF];
+    const int step = blockIdx.z;
+    const float* prm = params + steps.off[step];
+    float* h2P = h2all + (int64_t)step * h2_step_stride;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int net = wave & 1, jc = wave >> 1;
+    const int W2 = g.W + 2;
+    const int tpi = g.TH * g.TW;              // tiles per image
+
+    // ---- transform role: (tile, channel quad, half) ---------------------------------------------------------------------
+    // B^T d along the window's rows, for the rows i = 2*half, 2*half + 1 of the transformed domain:
+    //   half 0:  R0 = d0 - d2,  R1 = d1 + d2          half 1:  R2 = d2 - d1,  R3 = d1 - d3
+    // i.e. first = A - B, second = (half ? B - C : C + B) with window rows (A, B, C) = (0, 2, 1) / (2, 1, 3): rows A and B are
+    // loaded first, row C later into A's registers (32 staging registers instead of 48).
+    const int tt = (tid & 255) >> 3, tq = tid & 7, half = tid >> 8;
+    int offA, offB, offC;                     // float offsets of the three window rows' first pixel, channel quad tq
+    int cstep3;                               // step to the window's last column, clamped at the ring's edge (odd plane width)
+    {
+        int gt = blockIdx.x * 32 + tt;
+        if (gt >= g.ntiles) gt = g.ntiles - 1;
+        int b = gt / tpi, rem = gt - b * tpi;
+        int tr = rem / g.TW, tc = rem - tr * g.TW;
+        int x0 = 2 * tc;                      // ring coordinates
+        int yA = 2 * tr + (half ? 2 : 0), yB = 2 * tr + (half ? 1 : 2), yC = 2 * tr + (half ? 3 : 1);
+        if (yA > g.H + 1) yA = g.H + 1;       // odd plane height: the clamped rows only reach outputs that are not stored
+        if (yB > g.H + 1) yB = g.H + 1;
+        if (yC > g.H + 1) yC = g.H + 1;
+        cstep3 = (x0 + 3 > g.W + 1 ? 2 : 3) * IFL_FT;
+        const int img = b * (g.H + 2);
+        offA = ((img + yA) * W2 + x0) * IFL_FT + tq * 4;
+        offB = ((img + yB) * W2 + x0) * IFL_FT + tq * 4;
+        offC = ((img + yC) * W2 + x0) * IFL_FT + tq * 4;
+    }
+    // ---- output role: wave jc owns pixel (dy, dx) of tile j ---------------------------------------------------------------
+    int64_t opix[1];
+    {
+        int gt = blockIdx.x * 32 + j;
+        bool valid = gt < g.ntiles;
+        if (!valid) gt = g.ntiles - 1;
+        int b = gt / tpi, rem = gt - b * tpi;
+        int tr = rem / g.TW, tc = rem - tr * g.TW;
+        int y = 2 * tr + (jc >> 1), x = 2 * tc + (jc & 1);
+        valid = valid && y < g.H && x < g.W;
+        opix[0] = valid ? ((int64_t)(b * (g.H + 2) + y + 1) * W2 + x + 1) : -1;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+
+    constexpr int WD = 4;
+    constexpr int ITERS = 16;                 // 4 k-steps of 8 channels x 4 positions i per chunk
+    static_assert(ITERS % WD == 0, "ring slots must be compile-time");
+    const float* wnet = prm + off.w1w[net] + (int64_t)jc * (NCC * ITERS * 2 * 256) + lane * 4;
+    f32x4 wq[WD][2];
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wq[d][m] = *(const f32x4*)(wnet + (d * 2 + m) * 256);
+
+    const int vwr = ((half * 8) * 32 + tt) * WV_TS + tq * 4;          // V[4*(2*half) + 0][tt][tq*4]
+    const int vrd = (jc * 32 + j) * WV_TS + h * 4;                    // V[jc][j][4h]
+
+    // one row R of B^T d -> the four columns of R B, written to V[4i + 0..3][tile][quad]
+    auto put_row = [&](float* dst, const f32x4 (&R)[4]) {
+        *(f32x4*)(dst) = R[0] - R[2];
+        *(f32x4*)(dst + 32 * WV_TS) = R[1] + R[2];
+        *(f32x4*)(dst + 2 * 32 * WV_TS) = R[2] - R[1];
+        *(f32x4*)(dst + 3 * 32 * WV_TS) = R[1] - R[3];
+    };
+
+    f32x4 wa[4], wb[4];                       // window rows A (later C) and B of the chunk being transformed
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        wa[c] = *(const f32x4*)(ftP + offA + (c < 3 ? c * IFL_FT : cstep3));
+        wb[c] = *(const f32x4*)(ftP + offB + (c < 3 ? c * IFL_FT : cstep3));
+    }
+    {                                         // chunk 0 is transformed up front; later chunks inside the GEMM loop
+        f32x4 R[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[c] = wa[c] - wb[c];
+        put_row(lds + vwr, R);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)(ftP + offC + (c < 3 ? c * IFL_FT : cstep3));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[c] = wb[c] + (half ? -wa[c] : wa[c]);
+        put_row(lds + vwr + 4 * 32 * WV_TS, R);
+    }
+
+    for (int cc = 0; cc < NCC; ++cc) {
+        const float* vr = lds + (cc & 1) * WV_BUF + vrd;
+        float* vnext = lds + ((cc + 1) & 1) * WV_BUF + vwr;
+        const bool more = cc + 1 < NCC;
+        const int coff = (cc + 1) * IFL_CK;
+        __syncthreads();                      // V[cc & 1] complete; everyone is past the GEMM of chunk cc - 1, so
+                                              // V[(cc + 1) & 1] may be overwritten while this chunk is multiplied
+        const float* wc = wnet + (int64_t)cc * (ITERS * 2 * 256);
+        f32x4 xb[2];
+        xb[0] = *(const f32x4*)(vr);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {  // it = kq * 4 + i: consecutive k-steps go to different accumulators
+            if (it + 1 < ITERS) {
+                const int kq = (it + 1) >> 2, i = (it + 1) & 3;
+                xb[(it + 1) & 1] = *(const f32x4*)(vr + (i * 4) * 32 * WV_TS + kq * 8);
+            }
+            // the next chunk's window: rows A, B requested at it 0, used at it 7, where row C is requested, used at it 14
+            if (it == 0 && more) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    wa[c] = *(const f32x4*)(ftP + offA + (c < 3 ? c * IFL_FT : cstep3) + coff);
+                    wb[c] = *(const f32x4*)(ftP + offB + (c < 3 ? c * IFL_FT : cstep3) + coff);
+                }
+            }
+            if (it == 7 && more) {
+                f32x4 R[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) R[c] = wa[c] - wb[c];
+                put_row(vnext, R);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)(ftP + offC + (c < 3 ? c * IFL_FT : cstep3) + coff);
+            }
+            if (it == 14 && more) {
+                f32x4 R[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) R[c] = wb[c] + (half ? -wa[c] : wa[c]);
+                put_row(vnext + 4 * 32 * WV_TS, R);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[it & 3][m] = mfma32(wq[it % WD][m][e], xb[it & 1][e], acc[it & 3][m]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                wq[it % WD][m] = *(const f32x4*)(wc + ((it + WD) * 2 + m) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- A^T along i (local), A along jc (through LDS, one network at a time: 64 KB) ------------------------------------
+    f32x16 y[2][1];
+    float* X = lds;                           // X[jc][dy][m][r][lane]
+    for (int n = 0; n < 2; ++n) {
+        __syncthreads();                      // GEMM reads (n = 0) / the other network's exchange (n = 1) are over
+        if (net == n) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t0 = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+                    float t1 = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+                    X[(((jc * 2 + 0) * 2 + m) * 16 + r) * 64 + lane] = t0;
+                    X[(((jc * 2 + 1) * 2 + m) * 16 + r) * 64 + lane] = t1;
+                }
+        }
+        __syncthreads();
+        if (net == n) {
+            const int dy = jc >> 1, dx = jc & 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* xp = X + ((dy * 2 + m) * 16 + r) * 64 + lane;
+                    // dx = 0: (x0 + x1) + x2;  dx = 1: (x1 - x2) - x3 -- as selects, so the unrolled code has no branches
+                    float x0 = xp[0], x1 = xp[1 * 4 * 16 * 64], x2 = xp[2 * 4 * 16 * 64], x3 = xp[3 * 4 * 16 * 64];
+                    float u = dx ? x1 : x0, w = dx ? -x2 : x1, t = dx ? -x3 : x2;
+                    y[m][0][r] = (u + w) + t;
+                }
+        }
+    }
+
+    if (net == 0) {
+        if (opix[0] >= 0) {
+            float* dst = h2P + opix[0] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(f32x4*)(dst + m * 32 + gq * 8) = f32x4{y[m][0][gq * 4], y[m][0][gq * 4 + 1],
+                                                             y[m][0][gq * 4 + 2], y[m][0][gq * 4 + 3]};
+        }
+    } else {
+        finish_and_store<1, IFL_H2>(y, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
+    }
+}
+
 // ---- bf16 variant of phase 1 (BASELINE.json configs[4]: bf16 coupling-network convs, fp32 ActNorm / log-det) ------------
 // Same tiling and data flow as conv1_ft_kernel; the two GEMMs run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate):
 //   * the conditioning patch is converted fp32 -> bf16 (round to nearest even, v_cvt_pk_bf16_f32) while it is staged
@@ -526,6 +744,22 @@ int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const 
     }
     if (level == 1) hipLaunchKernelGGL(conv1_ft_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
     else hipLaunchKernelGGL(conv1_ft_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                        int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st)
+{
+    if (nsteps <= 0) return 0;
+    const IflWGeom g = ifl_wgeom(B, H, W);
+    if ((int64_t)B * (H + 2) * (W + 2) * IFL_FT >= (int64_t)1 << 31) {
+        ifl_set_error("conv1_ft (Winograd): conditioning slab of %d x %d x %d exceeds 2^31 floats", B, H, W);
+        return IFL_ENOTSUP;
+    }
+    dim3 grid((g.ntiles + 31) / 32, 1, nsteps), block(512);
+    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+    else hipLaunchKernelGGL(conv1_ft_wino_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
     IFL_LAUNCH_CHECK();
     return 0;
 }

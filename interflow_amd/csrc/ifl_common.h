@@ -66,6 +66,7 @@ struct IflStepOff {       // float offsets inside one step's block
     int64_t anic_fwd, anic_inv;
     int64_t w1[2], an1[2], w2[2], an2[2], w3[2], b3[2];     // [0] = fAffine, [1] = fFeatures
     int64_t w1b[2], w2b;      // bf16 copies for the bf16 variant of conv1_ft: first conv over ft (both nets), fFeatures' 1x1
+    int64_t w1w[2];           // Winograd F(2x2,3x3) transforms U = G g G^T of the conditioning part of the first conv (both nets)
     int64_t total;
 };
 
@@ -89,9 +90,18 @@ static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_couplin
         for (int n = 0; n < 2; ++n) o.w1b[n] = take((int64_t)IFL_HID * 9 * IFL_FT / 2);      // 2 bf16 per float slot
         o.w2b = take(IFL_HID * IFL_HID / 2);
         take(4096);                                                // pad: the weight prefetch ring reads past a field's end
-    } else { o.w1b[0] = o.w1b[1] = o.w2b = 0; }
+        for (int n = 0; n < 2; ++n) o.w1w[n] = take((int64_t)16 * IFL_HID * IFL_FT);
+        take(4096);
+    } else { o.w1b[0] = o.w1b[1] = o.w2b = o.w1w[0] = o.w1w[1] = 0; }
     o.total = p;
     return o;
+}
+
+// ---- Winograd tiling of a level's plane: 2x2-pixel output tiles, enumerated in raster order over (image, tile row, tile
+// column); a workgroup takes 32 consecutive tiles, so only the very last workgroup of a launch can be partly filled. ------
+struct IflWGeom { int H, W, TH, TW, ntiles; };      // ntiles = B * TH * TW
+static inline IflWGeom ifl_wgeom(int B, int H, int W) {
+    IflWGeom g; g.H = H; g.W = W; g.TH = (H + 1) / 2; g.TW = (W + 1) / 2; g.ntiles = B * g.TH * g.TW; return g;
 }
 
 #define IFL_MAX_COND 16       // conditional steps per level (flow_model.py:42 K=16)
@@ -165,6 +175,8 @@ int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* w
 // conv1.hip
 int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                    int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, int bf16, hipStream_t st);
+int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                        int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine

@@ -21,7 +21,7 @@ FLOW_BF16_CONV1 = 2
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
- F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16) = range(17)
+ F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16, F_W1A_WINO, F_W1F_WINO) = range(19)
 
 
 class IflLayer(Structure):
@@ -102,6 +102,8 @@ def lib():
     L.ifl_quantize_u8_nhwc.restype = c_int
     L.ifl_set_schedule.argtypes = [c_int, c_int, c_int]
     L.ifl_set_schedule.restype = c_int
+    L.ifl_set_conv1_algo.argtypes = [c_int]
+    L.ifl_set_conv1_algo.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -117,7 +119,7 @@ def lib():
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
-           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_cond_prepare", "ifl_flow_pass",
+           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad")
 
@@ -127,6 +129,15 @@ K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_
 def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -1):
     """Stream plan of the flow drivers (see ifl_set_schedule in interflow_hip.h); -1 keeps a setting."""
     check(lib().ifl_set_schedule(aux_stream, groups, p1_chunk_steps), "ifl_set_schedule")
+
+
+CONV1_DIRECT, CONV1_WINOGRAD = 0, 1
+
+
+def set_conv1_algo(algo: int = -1) -> int:
+    """Algorithm of the fp32 bulk convolution (ifl_set_conv1_algo): CONV1_WINOGRAD (default) or CONV1_DIRECT; any other
+    value only queries.  Returns the previous setting."""
+    return int(lib().ifl_set_conv1_algo(algo))
 
 
 def prof_enable(kernel_ids=()):

@@ -59,6 +59,19 @@ def _pack_conv1(wt, zoff, kz):
     return np.concatenate(out)
 
 
+_WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+
+
+def _pack_conv1_wino(wt, zoff):
+    """Conditioning part of wt [64, Cin, 3, 3] -> Winograd F(2x2,3x3) domain U = G g G^T (float64, rounded once to fp32),
+    laid out [jc][cc][kq][i][mt][h][o][e]: position (i, jc) of the 4x4 domain, out channel mt*32 + o, in channel
+    cc*32 + kq*8 + h*4 + e (conv1.hip, conv1_ft_wino_kernel)."""
+    g = wt[:, zoff:zoff + N_RRDB_CH].astype(np.float64)                          # [64, 320, 3, 3]
+    u = np.einsum("ia,ocab,jb->ocij", _WINO_G, g, _WINO_G).astype(F32)           # [64, 320, 4, 4]
+    u = u.reshape(2, 32, 10, 4, 2, 4, 4, 4)                                      # mt o cc kq h e i jc
+    return np.ascontiguousarray(u.transpose(7, 2, 3, 6, 0, 4, 1, 5)).reshape(-1)
+
+
 def to_bf16_bits(a):
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)."""
     u = np.ascontiguousarray(a, F32).view(np.uint32)
@@ -169,6 +182,8 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
             put(fb3, bp)
             put(hip.F_W1A_BF16 if net == 0 else hip.F_W1F_BF16,
                 _pack_conv1_bf16(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
+            put(hip.F_W1A_WINO if net == 0 else hip.F_W1F_WINO,
+                _pack_conv1_wino(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
             if net == 1:
                 put(hip.F_W2F_BF16, _pack_conv2_bf16(prm[q + "2.weight"].astype(F32)))
     return float(np.sum(logs, dtype=F32)), float(sum_log_s)
