@@ -267,6 +267,16 @@ void conv1_ft_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, i
 // Epilogue: A^T along i is local to a wave; A along jc goes through LDS between the four waves of a network, after which
 // wave jc holds the pixels (dy, dx) = (jc >> 1, jc & 1) of the 32 tiles in the usual accumulator layout, so the ActNorm /
 // ReLU / 1x1 / store code of the direct kernel is shared.
+// Build with -DIFL_EXP_TIME to record per-workgroup timestamps (tools/exp_wg_timeline.py); never defined in the product build.
+#ifdef IFL_EXP_TIME
+__device__ unsigned long long ifl_dbg[8 * 65536];
+#define DBG_T(k) do { if (LVL == 1 && lane == 0 && (wave == 0 || wave == 4)) { \
+    unsigned long long t_ = wall_clock64(); \
+    int wgid_ = blockIdx.z * gridDim.x + blockIdx.x; \
+    if (wgid_ < 16384) ifl_dbg[((wgid_ * 2 + (wave >> 2)) * 8) + (k)] = t_; } } while (0)
+#else
+#define DBG_T(k) do {} while (0)
+#endif
 constexpr int WV_TS = 36;                     // words per (position, tile) row of V: 32 channels + 4 (conflict-free b128 reads)
 constexpr int WV_BUF = 16 * 32 * WV_TS;       // floats per V buffer (73,728 B)
 
@@ -283,9 +293,22 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int net = wave & 1, jc = wave >> 1;
+    // waves w and w + 4 share a SIMD: one wave of each network per SIMD, so that fFeatures' extra epilogue (ActNorm, 1x1
+    // conv) is spread over all four matrix cores
+    const int net = wave >> 2, jc = wave & 3;
     const int W2 = g.W + 2;
     const int tpi = g.TH * g.TW;              // tiles per image
+    // Workgroups go to the 8 XCDs round-robin (linear id % 8).  Give each XCD a contiguous eighth of the tile groups, so
+    // that the window rows a group shares with the groups above and below it are found in that XCD's L2.
+    int grp = blockIdx.x;
+    if ((gridDim.x & 7) == 0) grp = (grp & 7) * (gridDim.x >> 3) + (grp >> 3);
+    DBG_T(0);
+#ifdef IFL_EXP_TIME
+    if (LVL == 1 && lane == 0 && wave == 0) {   // HW_REG_XCC_ID, HW_REG_HW_ID: which CU this workgroup runs on
+        int wgid_ = blockIdx.z * gridDim.x + blockIdx.x;
+        if (wgid_ < 16384) ifl_dbg[(wgid_ * 2) * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+#endif
 
     // ---- transform role: (tile, channel quad, half) ---------------------------------------------------------------------
     // B^T d along the window's rows, for the rows i = 2*half, 2*half + 1 of the transformed domain:
@@ -296,7 +319,7 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
     int offA, offB, offC;                     // float offsets of the three window rows' first pixel, channel quad tq
     int cstep3;                               // step to the window's last column, clamped at the ring's edge (odd plane width)
     {
-        int gt = blockIdx.x * 32 + tt;
+        int gt = grp * 32 + tt;
         if (gt >= g.ntiles) gt = g.ntiles - 1;
         int b = gt / tpi, rem = gt - b * tpi;
         int tr = rem / g.TW, tc = rem - tr * g.TW;
@@ -314,7 +337,7 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
     // ---- output role: wave jc owns pixel (dy, dx) of tile j ---------------------------------------------------------------
     int64_t opix[1];
     {
-        int gt = blockIdx.x * 32 + j;
+        int gt = grp * 32 + j;
         bool valid = gt < g.ntiles;
         if (!valid) gt = g.ntiles - 1;
         int b = gt / tpi, rem = gt - b * tpi;
@@ -371,6 +394,7 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
         put_row(lds + vwr + 4 * 32 * WV_TS, R);
     }
 
+    DBG_T(1);
     for (int cc = 0; cc < NCC; ++cc) {
         const float* vr = lds + (cc & 1) * WV_BUF + vrd;
         float* vnext = lds + ((cc + 1) & 1) * WV_BUF + vwr;
@@ -421,38 +445,46 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
         }
     }
 
-    // ---- A^T along i (local), A along jc (through LDS, one network at a time: 64 KB) ------------------------------------
+    // ---- A^T along i (local), A along jc through LDS: X[net][jc][dy][m][r / 4][lane][r % 4], 128 KB ----------------------
     f32x16 y[2][1];
-    float* X = lds;                           // X[jc][dy][m][r][lane]
-    for (int n = 0; n < 2; ++n) {
-        __syncthreads();                      // GEMM reads (n = 0) / the other network's exchange (n = 1) are over
-        if (net == n) {
+    DBG_T(2);
+    __syncthreads();                          // every wave's GEMM reads of V are over
+    DBG_T(3);
+    {
+        float* xw = lds + (net * 4 + jc) * (2 * 2 * 4 * 256) + lane * 4;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float t0 = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
-                    float t1 = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
-                    X[(((jc * 2 + 0) * 2 + m) * 16 + r) * 64 + lane] = t0;
-                    X[(((jc * 2 + 1) * 2 + m) * 16 + r) * 64 + lane] = t1;
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 t0, t1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = gq * 4 + e;
+                    t0[e] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+                    t1[e] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
                 }
-        }
-        __syncthreads();
-        if (net == n) {
-            const int dy = jc >> 1, dx = jc & 1;
+                *(f32x4*)(xw + ((0 * 2 + m) * 4 + gq) * 256) = t0;
+                *(f32x4*)(xw + ((1 * 2 + m) * 4 + gq) * 256) = t1;
+            }
+    }
+    __syncthreads();
+    {
+        // pixel (dy, dx) of the tile: dx = 0: (x0 + x1) + x2;  dx = 1: (x1 - x2) - x3  ==  (p + s q) + s r, s = +-1 (exact)
+        const int dy = jc >> 1, dx = jc & 1;
+        const float sg = dx ? -1.f : 1.f;
+        const float* xr = lds + (net * 4 + dx) * (2 * 2 * 4 * 256) + dy * (2 * 4 * 256) + lane * 4;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float* xp = X + ((dy * 2 + m) * 16 + r) * 64 + lane;
-                    // dx = 0: (x0 + x1) + x2;  dx = 1: (x1 - x2) - x3 -- as selects, so the unrolled code has no branches
-                    float x0 = xp[0], x1 = xp[1 * 4 * 16 * 64], x2 = xp[2 * 4 * 16 * 64], x3 = xp[3 * 4 * 16 * 64];
-                    float u = dx ? x1 : x0, w = dx ? -x2 : x1, t = dx ? -x3 : x2;
-                    y[m][0][r] = (u + w) + t;
-                }
-        }
+            for (int gq = 0; gq < 4; ++gq) {
+                const float* xp = xr + (m * 4 + gq) * 256;
+                f32x4 p = *(const f32x4*)(xp), q = *(const f32x4*)(xp + 2 * 2 * 4 * 256), r = *(const f32x4*)(xp + 2 * 2 * 2 * 4 * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[m][0][gq * 4 + e] = (p[e] + sg * q[e]) + sg * r[e];
+            }
     }
 
+    DBG_T(4);
     if (net == 0) {
         if (opix[0] >= 0) {
             float* dst = h2P + opix[0] * IFL_H2 + 4 * h;
@@ -466,6 +498,7 @@ void conv1_ft_wino_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
     } else {
         finish_and_store<1, IFL_H2>(y, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
     }
+    DBG_T(5);
 }
 
 // ---- bf16 variant of phase 1 (BASELINE.json configs[4]: bf16 coupling-network convs, fp32 ActNorm / log-det) ------------
@@ -763,6 +796,10 @@ int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, c
     IFL_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef IFL_EXP_TIME
+extern "C" int ifl_dbg_read(void* host, size_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ifl_dbg), bytes); }
+#endif
 
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st)

@@ -160,6 +160,44 @@ def test_full160_golden(golden_dir, sd_np, model):
     print(f"full160 rel errs: z {e1:.2e} logdet {e2:.2e} x {e3:.2e} logdet_rev {e4:.2e}")
 
 
+@pytest.mark.parametrize("algo", [hip.CONV1_DIRECT, hip.CONV1_WINOGRAD])
+def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
+    """Both forms of the bulk convolution (direct implicit GEMM, Winograd F(2x2,3x3)) meet the tolerance against the
+    reference's outputs on the 160x160 fixture, on an image whose deeper planes have odd sizes (20x36 -> 5x9: the
+    Winograd tiles overhang the plane) and on a single conditional step with a 1x1 plane."""
+    prev = hip.set_conv1_algo(algo)
+    try:
+        assert hip.set_conv1_algo(-1) == algo
+        g = load(golden_dir, "full160_seed0.npz", sd_np)
+        B, H = 2, 160
+        x = t(synth.synth_images(1, B, H, H)).to(dev())
+        feats = {k: t(v).to(dev()) for k, v in synth.synth_features(2, B, H, H).items()}
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        e1 = rel_close(z, g["z"], what="z"); e2 = rel_close(ld, g["ld"], what="logdet")
+        xr, ldr = model(t(g["z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        e3 = rel_close(xr, g["xr"], what="x"); rel_close(ldr, g["ldr"], what="logdet rev")
+        print(f"conv1 algo {algo}: rel errs z {e1:.2e} logdet {e2:.2e} x {e3:.2e}")
+        g = load(golden_dir, "stack32_seed0.npz", sd_np)
+        fu = model.flow_upsampler
+        x = t(synth.synth_images(13, 1, 20, 36)).to(dev())
+        feats = {k: t(v).to(dev()) for k, v in synth.synth_features(14, 1, 20, 36).items()}
+        z, ld = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+        rel_close(z, g["odd_z"], what="odd z"); rel_close(ld, g["odd_ld"], what="odd logdet")
+        xr, ldr = fu(z=t(g["odd_z"]).to(dev()), rrdbResults=feats, logdet=0., reverse=True)
+        rel_close(xr, g["odd_xr"], what="odd x"); rel_close(ldr, g["odd_ldr"], what="odd logdet rev")
+        for li, hw in ((22, (1, 1)), (5, (3, 5)), (30, (7, 2))):
+            step = fu.layers[li]
+            gen = torch.Generator().manual_seed(li)
+            zz = torch.randn(2, step.in_channels, *hw, generator=gen)
+            ft = torch.randn(2, 320, *hw, generator=gen)
+            l0 = torch.zeros(2)
+            zw, lw = O.flow_step(zz, l0, False, ft, sd, f"flow_upsampler.layers.{li}.")
+            out, ldo = step(zz.to(dev()), l0.to(dev()), reverse=False, rrdbResults=ft.to(dev()))
+            rel_close(out, zw, what=f"step {li} {hw} z"); rel_close(ldo, lw, 2e-4, what=f"step {li} {hw} logdet")
+    finally:
+        hip.set_conv1_algo(prev)
+
+
 def test_batch32_properties(golden_dir, sd_np, model):
     """BASELINE.json configs[1]: batch 32.  Size-independent properties: samples are independent (the first two
     reproduce the B=2 golden), decode inverts encode, and the log-dets cancel."""

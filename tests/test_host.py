@@ -90,3 +90,39 @@ def test_cpu_tensors_are_rejected(model):
         model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
     with pytest.raises(NotImplementedError):
         model(None, x, reverse=True)                              # flow_model.py:85-86
+
+
+def test_winograd_weight_transform_reproduces_the_direct_convolution():
+    """pack._pack_conv1_wino: U = G g G^T in the kernel's layout.  Unpacked and pushed through the data and output
+    transforms of conv1_ft_wino_kernel (restated here in numpy, including the clamped window of an odd-sized plane), it
+    must give the direct 3x3 correlation (flow.py:25-64, padding "same")."""
+    from interflow_amd import pack
+    rng = np.random.default_rng(0)
+    zoff = 6
+    wt = rng.standard_normal((64, zoff + 320, 3, 3)).astype(np.float32)
+    blob = pack._pack_conv1_wino(wt, zoff)
+    assert blob.dtype == np.float32 and blob.size == 16 * 64 * 320
+    u = blob.reshape(4, 10, 4, 4, 2, 2, 32, 4)                     # jc cc kq i mt h o e
+    U = np.zeros((64, 320, 4, 4), np.float32)
+    for jc in range(4):
+        for i in range(4):
+            U[:, :, i, jc] = u[jc, :, :, i].transpose(2, 4, 0, 1, 3, 5).reshape(64, 320)
+    H, W = 5, 3
+    x = np.zeros((H + 2, W + 2, 320), np.float32)
+    x[1:-1, 1:-1] = rng.standard_normal((H, W, 320))
+    g = wt[:, zoff:].astype(np.float64)
+    ref = np.zeros((H, W, 64))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum("yxc,oc->yxo", x[ky:ky + H, kx:kx + W].astype(np.float64), g[:, :, ky, kx])
+    TH, TW = (H + 1) // 2, (W + 1) // 2
+    out = np.zeros((2 * TH, 2 * TW, 64), np.float32)
+    for tr in range(TH):
+        for tc in range(TW):
+            d = np.stack([np.stack([x[min(2 * tr + r, H + 1), min(2 * tc + c, W + 1)] for c in range(4)]) for r in range(4)])
+            R = np.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])
+            V = np.stack([R[:, 0] - R[:, 2], R[:, 1] + R[:, 2], R[:, 2] - R[:, 1], R[:, 1] - R[:, 3]], axis=1)
+            M = np.einsum("ocij,ijc->ijo", U, V)
+            T = np.stack([M[0] + M[1] + M[2], M[1] - M[2] - M[3]])
+            out[2 * tr:2 * tr + 2, 2 * tc:2 * tc + 2] = np.stack([T[:, 0] + T[:, 1] + T[:, 2], T[:, 1] - T[:, 2] - T[:, 3]], axis=1)
+    assert np.abs(out[:H, :W] - ref).max() <= 1e-5 * np.abs(ref).max()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_profile.sh (condensed by prof_summary.py).
+
+usage: python tools/make_traffic.py <pmc_fetch.csv> <pmc_write.csv> <out.json> [tag used in the note, e.g. r01]
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB, separate
+passes; FETCH_SIZE counts a 128-byte read request as 64 bytes, so it is doubled; WRITE_SIZE is taken as read."""
+import csv
+import json
+import sys
+
+
+def col(path, name):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        v = r.get(name + "_avg_per_dispatch")
+        if v not in (None, ""):
+            out[r["kernel"]] = (float(v), int(r["calls"]))
+    return out
+
+
+def main():
+    fetch, write, dst = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "rNN"
+    f, w = col(fetch, "FETCH_SIZE"), col(write, "WRITE_SIZE")
+    res = {}
+    for k in f:
+        if not k.startswith("conv1_ft") or k not in w:
+            continue
+        res[k] = {
+            "bytes_per_launch": (2.0 * f[k][0] + w[k][0]) * 1024.0,
+            "fetch_size_kib_raw": f[k][0], "write_size_kib_raw": w[k][0], "dispatches": f[k][1],
+            "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{tag}_pmc_fetch.csv, "
+                    f"{tag}_pmc_write.csv; tools/gpu_profile.sh, tools/make_traffic.py), mean per dispatch of 8 conditional steps; "
+                    "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md section HBM), "
+                    "WRITE_SIZE as read; KiB -> bytes.  Infinity-Cache hits are included in FETCH_SIZE, so this is an upper "
+                    "bound on HBM bytes.  Algorithmic bytes per level-1 launch: ft plane once 275 MB + weights 21 MB + h2 slabs "
+                    "839 MB = 1.14 GB; the excess is the conditioning plane streamed again for each of the 8 steps of a launch "
+                    "(it does not fit the 4 MB L2s) with the halo of the 2x2-tile windows."}
+    json.dump(res, open(dst, "w"), indent=1)
+    print(json.dumps({k: v["bytes_per_launch"] for k, v in res.items()}))
+
+
+if __name__ == "__main__":
+    main()
