@@ -38,6 +38,10 @@ for w, name in ((0, "fAffine wave"), (1, "fFeatures wave")):
     d = t[:, w, :6]
     print(name, "median ns: prologue %.0f  loop %.0f  wait-barrier %.0f  exchange %.0f  finish %.0f  total %.0f" % tuple(
         np.median(ns(x)) for x in (d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 4] - d[:, 3], d[:, 5] - d[:, 4], d[:, 5] - d[:, 0])))
+d = t[:, 1, :]
+if (d[:, 6] > 0).all():
+    print("fFeatures finish split, median ns: ActNorm1 %.0f  1x1 MFMA %.0f  ActNorm2+stores %.0f" % (
+        np.median(ns(d[:, 6] - d[:, 4])), np.median(ns(d[:, 7] - d[:, 6])), np.median(ns(d[:, 5] - d[:, 7]))))
 start = t[:, :, 0].min(axis=1); end = t[:, :, 5].max(axis=1)
 gaps, per_cu = [], []
 for c in np.unique(cuid):
