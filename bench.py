@@ -180,7 +180,7 @@ def main():
             hip.prof_enable([])
             serial = {"ms_per_step": serial_elapsed / args.steps * 1e3, "dominant_avg_launch_ms": s_ms / max(s_n, 1)}
             names = (("conv1_ft_l1", hip.K_CONV1_FT_L1), ("conv1_ft_l2", hip.K_CONV1_FT_L2),
-                     ("conv1_finish", hip.K_CONV1_FINISH),
+                     ("conv3_f", hip.K_CONV3_F), ("conv1_finish", hip.K_CONV1_FINISH),
                      ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
             hip.prof_enable([k for _, k in names])
             step()

@@ -103,8 +103,9 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
  * weights, not on the tensor flowing through the stack.  The reference recomputes it in every pass; its own callers run
  * several passes over one conditioning (weighted_interpolate_image, flow_model.py:194-200: two encodes and one decode;
  * generate_images.py:60-81: 19 weights per image; train.py:73,85-86,94: three encodes and one decode share lr_enc).
- * ifl_cond_prepare computes that part once for every conditional step into the workspace (after ifl_load_cond of both
- * levels); ifl_flow_pass with IFL_FLOW_COND_PREPARED then runs only the part of the stack that depends on the running
+ * So does the whole of fFeatures (its input is the conditioning alone): its shift / scale and the sums of log(scale).
+ * ifl_cond_prepare computes both once for every conditional step into the workspace (after ifl_load_cond of both
+ * levels; `eps` must be the one the passes use: it is part of fFeatures' scale); ifl_flow_pass with IFL_FLOW_COND_PREPARED then runs only the part of the stack that depends on the running
  * tensor.  The prepared state lives in `ws` and stays valid until ifl_load_cond, ifl_flow_encode/decode (which prepare
  * on their own), ifl_flow_step or ifl_ws_init touch that workspace, or the parameters change.  Results are identical,
  * bit for bit, to ifl_flow_encode / ifl_flow_decode (same kernels, same order of operations).
@@ -117,7 +118,7 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
  * accuracy; against the fp32 reference the outputs differ by the bf16 rounding (tolerance: tests/test_gpu_parity.py). */
 #define IFL_FLOW_BF16_CONV1 2
 int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
-                     int flags, void* stream);
+                     float eps, int flags, void* stream);
 int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src, float* dst,
                   const float* logdet_in, float* logdet_out, int B, int H, int W, float eps, int decode, int flags,
                   void* stream);
@@ -218,7 +219,7 @@ enum {
     IFL_K_CONV1_FT_L1 = 0,    /* conv1_ft_kernel (conditioning part of both networks), level 1 (C = 12) */
     IFL_K_CONV1_FT_L2 = 1,    /* same, level 2 (C = 48) */
     IFL_K_CONV1_FINISH = 2,   /* conv1_finish_kernel (fAffine's z1 taps + epilogue) */
-    IFL_K_RESERVED = 3,
+    IFL_K_CONV3_F = 3,        /* conv3f_kernel: fFeatures' last conv + shift/scale for the steps of a bulk launch */
     IFL_K_CONV3_ENC = 4,
     IFL_K_CONV3_DEC = 5,
     IFL_K_ANIC = 6

@@ -138,8 +138,14 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
         lv.ha = take(ring * IFL_HID);
+        lv.sf_step = ring * 2 * lv.C;
+        lv.sf = take(lv.sf_step * IFL_MAX_COND);
         lv.geom = ifl_choose_geom(lv.H, lv.W);
-        slots += 2 * 16 * lv.geom.ntiles;
+        slots += IFL_MAX_COND * lv.geom.ntiles;
+    }
+    for (int l = 0; l < IFL_MAX_LEVELS; ++l) {          // fFeatures' sums behind the chain's slots
+        w.lv[l].ld_f0 = slots;
+        slots += IFL_MAX_COND * w.lv[l].geom.ntiles;
     }
     w.ld_slots = ifl_roundup(slots, 64);
     w.ldpart = take((int64_t)B * w.ld_slots);
@@ -192,8 +198,9 @@ extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const flo
 }
 
 // ---- one FlowStep on a level's ringed buffers -------------------------------------------------------------------
-// `h2` is the step's slab of hidden activations; its conditioning-only part (phase 1, conv1_ft_kernel) is already there.
-static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, float* h2,
+// `slab` is the step's index among the level's conditional steps: its h2 slab holds the conditioning-only part of the first
+// conv (conv1_ft) and its sf slab fFeatures' shift / scale (conv3f); both are written by phase 1.
+static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
                        int& slots, double& constant, float eps, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
@@ -204,31 +211,33 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
     if (L.kind == 2) {
+        const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
+        const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
         { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_ENC, st);
-          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
+          rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
     return 0;
 }
 
-static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, float* h2,
+static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
                        int& slots, double& constant, float eps, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
     int rc;
     if (L.kind == 2) {
-        { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 1, eps, st); }
+        const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
+        const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
+        { ProfScope ps(IFL_K_CONV3_DEC, st); rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st); }
         if (rc) return rc;
-        slots += lv.geom.ntiles;
         { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(h2, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
+          rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
@@ -324,12 +333,23 @@ int& conv1_algo()
     return a;
 }
 
-int conv1_ft(const IflLevelWs& lv, float* h2, const float* params, const IflStepList& steps, int nsteps, const IflStepOff& off,
-             int B, int level, int bf16, hipStream_t st)
+// The z-independent work of the conditional steps [s0, s0 + nsteps) of a level (`steps` lists their parameter blocks):
+// both networks' first conv over the conditioning features into the h2 slabs, then fFeatures' last conv -> sf slabs and
+// its log-det sums.
+int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params, const IflStepList& steps, int nsteps,
+               const IflStepOff& off, int level, int bf16, float eps, hipStream_t st)
 {
-    if (!bf16 && conv1_algo() == 1)
-        return ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, B, lv.H, lv.W, level, st);
-    return ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, B, level, bf16, st);
+    float* h2 = lv.h2 + (int64_t)s0 * lv.h2_step;
+    int rc;
+    { ProfScope ps(level == 1 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
+      if (!bf16 && conv1_algo() == 1)
+          rc = ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
+      else
+          rc = ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st); }
+    if (rc) return rc;
+    ProfScope ps(IFL_K_CONV3_F, st);
+    return ifl_k_conv3f(h2, lv.h2_step, lv.sf + (int64_t)s0 * lv.sf_step, lv.sf_step, w.ldpart, w.ld_slots,
+                        lv.ld_f0 + s0 * lv.geom.ntiles, params, steps, nsteps, off, lv.geom, w.B, lv.C, eps, st);
 }
 
 int n_groups(int B)
@@ -347,7 +367,8 @@ IflWs ws_slice(const IflWs& w, int b0, int nb)
     for (int l = 0; l < IFL_MAX_LEVELS; ++l) {
         IflLevelWs& lv = s.lv[l];
         int64_t ring = (int64_t)b0 * (lv.H + 2) * (lv.W + 2);
-        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2; lv.ha += ring * IFL_HID;     // h2_step stays the full-batch slab stride
+        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2; lv.ha += ring * IFL_HID;     // h2_step, sf_step stay the full-batch slab strides
+        lv.sf += ring * 2 * lv.C;
     }
     s.ldpart += (int64_t)b0 * w.ld_slots;
     return s;
@@ -374,7 +395,7 @@ int make_plan(const ifl_layer* layers, int n_layers, CondPlan* p)
 
 // phase 1 of one level: chunks of IFL_P1_CHUNK steps in the order given by `reverse`; event e0 + chunk index marks each
 int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* params, bool reverse, hipStream_t st,
-                  hipEvent_t* ev, int bf16, int chunk_override = 0)
+                  hipEvent_t* ev, int bf16, float eps, int chunk_override = 0)
 {
     const IflLevelWs& lv = w.lv[lvl];
     const int n = plan.n[lvl];
@@ -386,9 +407,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
         const int s0 = ci * chunk, s1 = s0 + chunk < n ? s0 + chunk : n;
         IflStepList sub{};
         for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
-        int rc;
-        { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = conv1_ft(lv, lv.h2 + (int64_t)s0 * lv.h2_step, params, sub, s1 - s0, off, w.B, lvl + 1, bf16, st); }
+        int rc = bulk_steps(w, lv, s0, params, sub, s1 - s0, off, lvl + 1, bf16, eps, st);
         if (rc) return rc;
         if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
     }
@@ -421,8 +440,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
             } else {
                 const int slab = plan.slab_of_layer[i];
                 if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
-                rc = step_encode(L, params, w, w.lv[lvl], w.lv[lvl].h2 + (int64_t)(slab < 0 ? 0 : slab) * w.lv[lvl].h2_step,
-                                 slots, constant, eps, st);
+                rc = step_encode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st);
             }
             if (rc) return rc;
         }
@@ -441,13 +459,14 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
             } else {
                 const int slab = plan.slab_of_layer[i];
                 if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
-                rc = step_decode(L, params, w, w.lv[lvl], w.lv[lvl].h2 + (int64_t)(slab < 0 ? 0 : slab) * w.lv[lvl].h2_step,
-                                 slots, constant, eps, st);
+                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st);
             }
             if (rc) return rc;
         }
     }
-    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
+    // fFeatures' sums of log(scale) (phase 1): subtracted by the encode direction, added by the decode direction
+    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, decode ? 1.0 : -1.0,
+                             w.lv[0].ld_f0, plan.n[0] * w.lv[0].geom.ntiles, w.lv[1].ld_f0, plan.n[1] * w.lv[1].geom.ntiles, B, st);
 }
 
 int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -477,7 +496,7 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
     // phase 1 in the order the chain consumes the levels
     for (int k = 0; k < IFL_MAX_LEVELS && !prepared; ++k) {
         const int lvl = decode ? IFL_MAX_LEVELS - 1 - k : k;
-        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev, bf16))) return rc;
+        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev, bf16, eps))) return rc;
     }
     if (use_aux) IFL_HIP(hipEventRecord(f->aux_done, f->aux));
     else if (G > 1) IFL_HIP(hipEventRecord(f->fork, st));        // groups start after phase 1 on the caller's stream
@@ -540,7 +559,7 @@ extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const floa
 }
 
 extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
-                                int flags, void* stream)
+                                float eps, int flags, void* stream)
 {
     IFL_CHECK_ARG((flags & ~IFL_FLOW_BF16_CONV1) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
     int rc = check_shape(B, H, W);
@@ -552,7 +571,8 @@ extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const flo
     CondPlan plan;
     if ((rc = make_plan(layers, n_layers, &plan))) return rc;
     for (int lvl = 0; lvl < IFL_MAX_LEVELS; ++lvl)      // one launch per level: all conditional steps at once
-        if ((rc = launch_phase1(w, lvl, plan, params, false, (hipStream_t)stream, nullptr, (flags & IFL_FLOW_BF16_CONV1) != 0, IFL_MAX_COND))) return rc;
+        if ((rc = launch_phase1(w, lvl, plan, params, false, (hipStream_t)stream, nullptr, (flags & IFL_FLOW_BF16_CONV1) != 0, eps,
+                                IFL_MAX_COND))) return rc;
     return 0;
 }
 
@@ -593,15 +613,14 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
     if (layer->kind == 2) {
         IflStepList one{};
         one.off[0] = layer->param_off;
-        { ProfScope ps(lvl == 0 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-          rc = conv1_ft(lv, lv.h2, params, one, 1, ifl_step_off(lv.C, 1), B, lvl + 1, 0, st); }
-        if (rc) return rc;
+        if ((rc = bulk_steps(w, lv, 0, params, one, 1, ifl_step_off(lv.C, 1), lvl + 1, 0, eps, st))) return rc;
     }
-    rc = reverse ? step_decode(*layer, params, w, lv, lv.h2, slots, constant, eps, st)
-                 : step_encode(*layer, params, w, lv, lv.h2, slots, constant, eps, st);
+    rc = reverse ? step_decode(*layer, params, w, lv, 0, slots, constant, eps, st)
+                 : step_encode(*layer, params, w, lv, 0, slots, constant, eps, st);
     if (rc) return rc;
     if ((rc = ifl_k_ring_to_nchw(lv.z, z_out, B, lv.C, lv.H, lv.W, st))) return rc;
-    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, 1.0, B, st);
+    return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, reverse ? 1.0 : -1.0,
+                             lv.ld_f0, layer->kind == 2 ? lv.geom.ntiles : 0, 0, 0, B, st);
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------------------------

@@ -116,14 +116,17 @@ struct IflLevelWs {
     float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step: [0:64] fAffine's
                               //   conditioning-only pre-activation sums, [64:128] fFeatures' finished hidden activations
     float* ha;                // [B][H+2][W+2][64]  zero ring; fAffine's finished hidden activations of the step in flight
-    int64_t h2_step;          // floats per step slab
+    float* sf;                // [IFL_MAX_COND][B][H+2][W+2][2C]  fFeatures' (shift c, scale c) pairs of every conditional step
+    int64_t h2_step, sf_step; // floats per step slab
+    int ld_f0;                // first ldpart slot of this level's fFeatures sums: [step][tile]
     IflGeom geom;
 };
 
 struct IflWs {
     int B, H, W;
     IflLevelWs lv[IFL_MAX_LEVELS];
-    float* ldpart;            // [B][ld_slots] per-tile log-det partial sums
+    float* ldpart;            // [B][ld_slots] per-tile log-det partial sums: the chain's (one per conditional step and tile, in the
+                              //   order the pass runs them), then per level fFeatures' [step][tile] (written by phase 1, kept)
     int ld_slots;
     int64_t bytes;
 };
@@ -166,8 +169,9 @@ int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, 
 int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st);
 // pointwise.hip
 int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st);            // in place on ringed NHWC
+// ld_out = ld_in + constant + sum ldpart[0, slots_used) + fsign * (sum ldpart[fa0, fa0+fan) + sum ldpart[fb0, fb0+fbn))
 int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
-                      double constant, double sign, int B, hipStream_t st);
+                      double constant, double fsign, int fa0, int fan, int fb0, int fbn, int B, hipStream_t st);
 int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* scratch,
                float* out, int B, int C, int HW, hipStream_t st);
 int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B,
@@ -179,6 +183,10 @@ int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, c
                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st);
-// conv3.hip:  mode: 0 = encode (both nets), 1 = decode fFeatures, 2 = decode fAffine
-int ifl_k_conv3(const float* h2, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
+// conv3.hip:  mode: 0 = encode (fAffine's conv, both couplings), 2 = decode (fAffine's conv and coupling)
+int ifl_k_conv3(const float* sf, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
                 const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st);
+int ifl_k_conv3f(const float* h2all, int64_t h2_step, float* sfall, int64_t sf_step, float* ldpart, int ld_slots, int slot0,
+                 const float* params, const IflStepList& steps, int nsteps, const IflStepOff& off, const IflGeom& g, int B, int C,
+                 float eps, hipStream_t st);
+int ifl_k_fapply(const float* sf, float* z, int B, int C, int H, int W, hipStream_t st);

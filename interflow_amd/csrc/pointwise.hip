@@ -58,11 +58,15 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
 
 __global__ __launch_bounds__(64)
 void ld_finalize_kernel(const float* __restrict__ ldpart, int used, int ld_slots, const float* __restrict__ ld_in,
-                        float* __restrict__ ld_out, double constant)
+                        float* __restrict__ ld_out, double constant, double fsign, int fa0, int fan, int fb0, int fbn)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    double s = 0.0;
-    for (int i = lane; i < used; i += 64) s += (double)ldpart[(int64_t)b * ld_slots + i];
+    const float* row = ldpart + (int64_t)b * ld_slots;
+    double s = 0.0, f = 0.0;
+    for (int i = lane; i < used; i += 64) s += (double)row[i];
+    for (int i = lane; i < fan; i += 64) f += (double)row[fa0 + i];
+    for (int i = lane; i < fbn; i += 64) f += (double)row[fb0 + i];
+    s += fsign * f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) ld_out[b] = (float)((double)(ld_in ? ld_in[b] : 0.f) + constant + s);
@@ -160,9 +164,10 @@ int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inve
 }
 
 int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
-                      double constant, double /*sign*/, int B, hipStream_t st)
+                      double constant, double fsign, int fa0, int fan, int fb0, int fbn, int B, hipStream_t st)
 {
-    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, ldpart, slots_used, ld_slots, ld_in, ld_out, constant);
+    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, ldpart, slots_used, ld_slots, ld_in, ld_out, constant,
+                       fsign, fa0, fan, fb0, fbn);
     IFL_LAUNCH_CHECK();
     return 0;
 }
@@ -176,7 +181,7 @@ int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float lo
     else if (C == 12) hipLaunchKernelGGL((logp_kernel<12>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
     else hipLaunchKernelGGL((logp_kernel<0>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
     IFL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, scratch, nblk, nblk, (const float*)nullptr, out, 0.0);
+    hipLaunchKernelGGL(ld_finalize_kernel, dim3(B), dim3(64), 0, st, scratch, nblk, nblk, (const float*)nullptr, out, 0.0, 0.0, 0, 0, 0, 0);
     IFL_LAUNCH_CHECK();
     return 0;
 }

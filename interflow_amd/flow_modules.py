@@ -373,7 +373,7 @@ class FlowUpsamplerNet(nn.Module):
         with torch.cuda.device(dev):
             self._load_cond(ws, enc, batch, H, W)
             hip.check(hip.lib().ifl_cond_prepare(layers, len(layers), hip._ptr(params), ws.ptr, batch, H, W,
-                                                 self._flags(), hip._stream()), "ifl_cond_prepare")
+                                                 float(self.affine_eps), self._flags(), hip._stream()), "ifl_cond_prepare")
         return PreparedCond(rrdbResults, ws, ws.generation, (self._packed[0], self.conv_dtype), enc, (batch, H, W))
 
     def _needs_autograd(self, src, rrdbResults):

@@ -68,7 +68,7 @@ def lib():
                  c_int, c_int, c_int, c_float, c_void_p]
     L.ifl_flow_encode.argtypes = flow_args
     L.ifl_flow_decode.argtypes = flow_args
-    L.ifl_cond_prepare.argtypes = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_cond_prepare.argtypes = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]
     L.ifl_flow_pass.argtypes = flow_args[:-1] + [c_int, c_int, c_void_p]
     L.ifl_flow_step.argtypes = [POINTER(IflLayer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
@@ -123,7 +123,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad")
 
-K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, _K_RESERVED, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
+K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
 
 def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -1):

@@ -128,12 +128,16 @@ def main():
         flop = 2.0 * sum((64 * 9 * (C // 2) + 64 * 64) * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
         add("conv1_finish_kernel", "fAffine z1 taps + ActNorm/ReLU/1x1 (Ablation.py:228-233)", "mfma", flop, s,
             "B=32, mean of the two levels")
-        for kid, fn, name in ((hip.K_CONV3_ENC, enc, "conv3_kernel<*,*,0> (encode)"),
-                              (hip.K_CONV3_DEC, dec, "conv3_kernel<*,*,1|2> (decode, two launches per step)")):
+        s, n = lib_time(hip.K_CONV3_F, enc)
+        flop = 2.0 * sum(64 * 9 * 2 * C * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
+        add("conv3f_kernel<*>", "fFeatures' Conv2dZeros 3x3 + sigmoid -> shift/scale slabs, sum log scale (flow.py:67-82, "
+            "Ablation.py:219-240); 8 steps per launch", "mfma", flop, s, "B=32, mean of the two levels")
+        for kid, fn, name, launches in ((hip.K_CONV3_ENC, enc, "conv3_kernel<*,*,0> (encode: fAffine conv + both couplings)", 1),
+                                        (hip.K_CONV3_DEC, dec, "fapply_kernel + conv3_kernel<*,*,2> (decode, per step)", 2)):
             s, n = lib_time(kid, fn)
-            flop = 2.0 * sum(64 * 9 * 3 * C * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
-            add(name, "Conv2dZeros 3x3 + sigmoid + affine coupling + sum log scale (flow.py:67-82, Ablation.py:167-240)",
-                "mfma", flop, s, "B=32, mean of the two levels")
+            flop = 2.0 * sum(64 * 9 * C * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 * launches / n
+            add(name, "fAffine's Conv2dZeros 3x3 + sigmoid + affine coupling(s) + sum log scale (flow.py:67-82, Ablation.py:167-240)",
+                "mfma", flop, s * launches, "B=32, mean of the two levels")
         s = ev_time(both, reps=5, warm=2)
         add("whole path (encode + decode), one stream", "InterpFlow.forward both directions", "mfma", 213.1e9 * B, s, "B=32")
     hip.set_schedule(aux_stream=1, groups=2)
