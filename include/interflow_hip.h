@@ -65,7 +65,9 @@ enum {
     IFL_F_W2F_BF16 = 16,                        /* bf16 copy of fFeatures' 1x1 conv, accumulator-as-operand k order       */
     IFL_F_W1A_WINO = 17, IFL_F_W1F_WINO = 18,   /* Winograd F(2x2,3x3) transform G g G^T of the conditioning part of W1A / W1F:
                                                    [column jc of the 4x4 domain][chunk][k-step][row i][m][MFMA A fragment]  */
-    IFL_F_COUNT = 19
+    IFL_F_W1A_WINO4 = 19, IFL_F_W1F_WINO4 = 20, /* Winograd F(4x4,3x3) transform (6x6 domain) of the same weights:
+                                                   [half of the outputs][3x3 block of positions][sub-chunk of 8 inputs][position][MFMA A fragment] */
+    IFL_F_COUNT = 21
 };
 int64_t ifl_step_param_floats(int C, int has_coupling);
 int64_t ifl_step_field_off(int C, int field);
@@ -134,9 +136,10 @@ int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, vo
  * events are created once per device at the first call that needs them.                                            */
 int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps);
 
-/* Algorithm of the z-independent bulk convolution in fp32 (no counterpart in the reference): 1 = Winograd F(2x2,3x3)
- * minimal filtering (default; 2.25x fewer multiplications, same fp32 arithmetic type, sums associated differently),
- * 0 = direct implicit GEMM.  Environment IFL_CONV1_WINO=0/1 sets the default at load.  Any other value only queries.
+/* Algorithm of the z-independent bulk convolution in fp32 (no counterpart in the reference): 2 = Winograd F(4x4,3x3)
+ * minimal filtering (default; 4x fewer multiplications than the direct form, same fp32 arithmetic type, sums associated
+ * differently), 1 = Winograd F(2x2,3x3) (2.25x fewer), 0 = direct implicit GEMM.  Environment IFL_CONV1_WINO=0/1/2 sets
+ * the default at load.  Any other value only queries.
  * Returns the previous setting.  The bf16 variant (IFL_FLOW_BF16_CONV1) always uses the direct form.                */
 int ifl_set_conv1_algo(int algo);
 

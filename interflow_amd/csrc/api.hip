@@ -90,6 +90,8 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
         case IFL_F_W2F_BF16: return o.w2b;
         case IFL_F_W1A_WINO: return o.w1w[0];
         case IFL_F_W1F_WINO: return o.w1w[1];
+        case IFL_F_W1A_WINO4: return o.w1x[0];
+        case IFL_F_W1F_WINO4: return o.w1x[1];
     }
     return -1;
 }
@@ -134,6 +136,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.C = 3 << (2 * (l + 1));
         int64_t ring = (int64_t)B * (lv.H + 2) * (lv.W + 2);
         lv.ft = take(ring * IFL_FT);
+        lv.ftp = take(ifl_ftp_floats(B, lv.H, lv.W));
         lv.z = take(ring * lv.C);
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
@@ -158,7 +161,7 @@ static int check_shape(int B, int H, int W, int div = 4)
 {
     IFL_CHECK_ARG(B >= 1 && H >= div && W >= div, IFL_EINVAL, "bad shape B=%d H=%d W=%d", B, H, W);
     IFL_CHECK_ARG(H % div == 0 && W % div == 0, IFL_EINVAL, "H=%d, W=%d must be multiples of %d (flow.py:172)", H, W, div);
-    IFL_CHECK_ARG((int64_t)(H / 2 + 2) * (W / 2 + 2) * IFL_FT < (int64_t)1 << 31, IFL_ENOTSUP,
+    IFL_CHECK_ARG((int64_t)(H / 2 + 6) * (W / 2 + 6) * IFL_FT < (int64_t)1 << 31, IFL_ENOTSUP,
                   "image plane too large for 32-bit tile offsets: tile the image");
     IFL_CHECK_ARG(B <= 65535, IFL_ENOTSUP, "B=%d exceeds the grid's y extent", B);
     return 0;
@@ -185,6 +188,15 @@ extern "C" int ifl_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, void
     return 0;
 }
 
+// both copies of a level's conditioning features: ringed channels-last (direct, F(2x2) and bf16 kernels, training) and
+// planar-8 (F(4x4) kernel)
+static int load_ft(const IflLevelWs& lv, int B, const float* ft_nchw, hipStream_t st)
+{
+    int rc = ifl_k_nchw_to_ring(ft_nchw, lv.ft, B, IFL_FT, lv.H, lv.W, st);
+    if (rc) return rc;
+    return ifl_k_nchw_to_planar8(ft_nchw, lv.ftp, B, IFL_FT, lv.H, lv.W, st);
+}
+
 extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const float* ft_nchw, void* stream)
 {
     int rc = check_shape(B, H, W);
@@ -193,8 +205,7 @@ extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const flo
     IFL_CHECK_ARG(level >= 1 && level <= IFL_MAX_LEVELS, IFL_EINVAL, "level %d outside 1..%d", level, IFL_MAX_LEVELS);
     IflWs w;
     ifl_ws_layout(ws, B, H, W, &w);
-    const IflLevelWs& lv = w.lv[level - 1];
-    return ifl_k_nchw_to_ring(ft_nchw, lv.ft, B, IFL_FT, lv.H, lv.W, (hipStream_t)stream);
+    return load_ft(w.lv[level - 1], B, ft_nchw, (hipStream_t)stream);
 }
 
 // ---- one FlowStep on a level's ringed buffers -------------------------------------------------------------------
@@ -326,10 +337,10 @@ Sched& sched()
     return s;
 }
 
-// algorithm of the bulk kernel (fp32): 1 = Winograd F(2x2,3x3) (default), 0 = direct implicit GEMM
+// algorithm of the bulk kernel (fp32): 2 = Winograd F(4x4,3x3) (default), 1 = Winograd F(2x2,3x3), 0 = direct implicit GEMM
 int& conv1_algo()
 {
-    static int a = env_int("IFL_CONV1_WINO", 1) ? 1 : 0;
+    static int a = [] { int v = env_int("IFL_CONV1_WINO", 2); return v < 0 || v > 2 ? 2 : v; }();
     return a;
 }
 
@@ -342,7 +353,9 @@ int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params
     float* h2 = lv.h2 + (int64_t)s0 * lv.h2_step;
     int rc;
     { ProfScope ps(level == 1 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-      if (!bf16 && conv1_algo() == 1)
+      if (!bf16 && conv1_algo() == 2)
+          rc = ifl_k_conv1_ft_wino4(lv.ftp, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
+      else if (!bf16 && conv1_algo() == 1)
           rc = ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
       else
           rc = ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st); }
@@ -521,7 +534,7 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
 extern "C" int ifl_set_conv1_algo(int algo)
 {
     int prev = conv1_algo();
-    if (algo == 0 || algo == 1) conv1_algo() = algo;
+    if (algo >= 0 && algo <= 2) conv1_algo() = algo;
     return prev;
 }
 
@@ -607,7 +620,7 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
     ifl_ws_layout(ws, B, H, W, &w);
     const IflLevelWs& lv = w.lv[lvl];
     if ((rc = ifl_k_nchw_to_ring(z_in, lv.z, B, lv.C, lv.H, lv.W, st))) return rc;
-    if (layer->kind == 2 && (rc = ifl_k_nchw_to_ring(ft, lv.ft, B, IFL_FT, lv.H, lv.W, st))) return rc;
+    if (layer->kind == 2 && (rc = load_ft(lv, B, ft, st))) return rc;
     int slots = 0;
     double constant = 0.0;
     if (layer->kind == 2) {

@@ -1,0 +1,363 @@
+// conv1x.hip -- the z-independent bulk convolution of the coupling networks by Winograd F(4x4,3x3) minimal filtering on the
+// fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Computes the same sums as conv1_ft_kernel / conv1_ft_wino_kernel of conv1.hip (reference interflow/models/modules:
+// flow.Conv2d 3x3 over the 320 conditioning channels of fFeatures and fAffine, flow.py:25-64,
+// FlowAffineCouplingsAblation.py:219-233,248-256, plus fFeatures' ActNorm / ReLU / 1x1 / ActNorm / ReLU) with 36
+// multiplications per 4x4 outputs, input channel and output channel instead of the direct form's 144 (F(2x2,3x3): 64):
+//   Y = A^T [ sum_ci U[co][ci] (.) V[ci] ] A,   U = G g G^T (host, float64 -> fp32, pack.py),   V = B^T d B
+// for every 4x4 output tile and its 6x6 input window d (Lavin & Gray's matrices for the points 0, +-1, +-2, inf).  For each of
+// the 36 positions (i, jc) of the transformed domain the sum over input channels is a GEMM
+//   M[co][tile] = U[co][ci] V[ci][tile]     (fp32 throughout; the result differs from the direct form by fp32 rounding only:
+//                                            tools/exp_wino_error.py, tests/test_gpu_parity.py).
+//
+// Workgroup = one network x 32 consecutive tiles (raster order over image, tile row, tile column) = 512 output pixels x 64
+// channels; 8 waves = 2 halves of the output channels x 4 blocks of 3x3 positions, 144 accumulator registers per wave.
+// The 320 input channels are walked in 40 sub-chunks of 8.  Per sub-chunk s, between two barriers:
+//   GEMM(s)      every wave: its 9 positions x 4 k-steps on V[s & 1] (one 16-byte LDS read per position), weights streamed
+//                global -> VGPR through a 6-deep ring (fragment order, contiguous per wave);
+//   pass 2(s+1)  waves 0-5: T[(s+1) & 1] -> V[(s+1) & 1], the transform along the window's columns (item = tile, row i, quad);
+//   pass 1(s+2)  waves 0-5: registers -> T[s & 1], the transform along the window's rows (item = tile, column c, quad) of the
+//                6 window pixels loaded one sub-chunk earlier; then the loads for sub-chunk s + 3.
+// The features are read from the planar-8 copy (ifl_common.h, IflXGeom): the 12 lanes of a tile cover the 192 contiguous
+// bytes of a window row, and zero padding up to whole tiles removes every bound test.
+// LDS: V and T double-buffered, each [36 positions][32 tiles][8 channels] (T rows 32 bytes apart more) -> 149,760 B.  A row's
+// two 16-byte quads are swapped for tiles 8-15 and 24-31, which makes the 16-byte reads bank-conflict free without
+// padding the tiles; the T row pitch does the same for the pass-1 stores.
+// Epilogue: the output transform A^T M A is linear, so each wave reduces its 3x3 block to partial sums and exchanges them
+// with its partner block through LDS, first along i, then along jc; afterwards wave (bi, bj) holds output pixels
+// (2 bi + {0,1}, 2 bj + {0,1}) of its 32 tiles and 32 channels in the usual accumulator layout.  fAffine's raw sums are stored
+// as they are; for fFeatures the two channel halves trade pixel sets and finish_and_store (conv1_fin.h) does the rest.
+#include "ifl_common.h"
+#include <type_traits>
+
+namespace {
+
+#include "conv1_fin.h"
+
+constexpr int XN = IFL_FT / IFL_XCH;          // 40 sub-chunks
+constexpr int XBUF = 36 * 32 * IFL_XCH;       // floats per V buffer
+constexpr int XTROW = 32 * IFL_XCH + 8;       // floats per (i, c) row of T: 8 more than it holds, so that the four columns a
+                                              // pass-1 store instruction covers fall into different banks
+constexpr int XTBUF = 36 * XTROW;
+constexpr int XRD = 6;                        // weight ring depth (positions)
+constexpr int XSLOT = 16 * 64;                // floats per exchanged f32x16 (all lanes)
+
+__device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 y) {
+    return f32x4{__builtin_fmaf(s, x[0], y[0]), __builtin_fmaf(s, x[1], y[1]), __builtin_fmaf(s, x[2], y[2]), __builtin_fmaf(s, x[3], y[3])};
+}
+
+// B^T x for one column / row of six values (B^T of F(4x4,3x3), points 0, +-1, +-2, inf):
+//   t0 = 4 x0 - 5 x2 + x4        t1,2 = (x4 - 4 x2) +- (x3 - 4 x1)        t3,4 = (x4 - x2) +- 2 (x3 - x1)        t5 = 4 x1 - 5 x3 + x5
+// `get(k)` yields x_k, `put(k, v)` consumes t_k; even inputs are fetched and folded first, so few values are live at a time.
+template <class Get, class Put>
+__device__ __forceinline__ void bt6(Get get, Put put) {
+    f32x4 a, c;
+    {
+        const f32x4 x2 = get(2), x4 = get(4);
+        a = fma4(-4.f, x2, x4);
+        c = x4 - x2;
+        put(0, fma4(4.f, get(0), fma4(-5.f, x2, x4)));
+    }
+    f32x4 b, e;
+    {
+        const f32x4 x1 = get(1), x3 = get(3);
+        b = fma4(-4.f, x1, x3);
+        e = x3 - x1;
+        put(5, fma4(4.f, x1, fma4(-5.f, x3, get(5))));
+    }
+    put(1, a + b);
+    put(2, a - b);
+    put(3, fma4(2.f, e, c));
+    put(4, fma4(-2.f, e, c));
+}
+
+__device__ __forceinline__ void st16(float* p, const f32x16& v) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) *(f32x4*)(p + gq * 256) = f32x4{v[gq * 4], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]};
+}
+__device__ __forceinline__ void add16(const float* p, f32x16& v) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        f32x4 x = *(const f32x4*)(p + gq * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[gq * 4 + e] += x[e];
+    }
+}
+__device__ __forceinline__ void ld16(const float* p, f32x16& v) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        f32x4 x = *(const f32x4*)(p + gq * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[gq * 4 + e] = x[e];
+    }
+}
+
+// One direction of the output transform for a wave that holds three consecutive of the six values (blk 0: 0,1,2; blk 1:
+// 3,4,5).  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  keep[0..1] are this block's parts of the two
+// outputs it finishes (outputs 2 blk, 2 blk + 1), send[0..1] its parts of the partner's two outputs.
+__device__ __forceinline__ void at_part(int blk, const f32x16& m0, const f32x16& m1, const f32x16& m2,
+                                        f32x16& k0, f32x16& k1, f32x16& s0, f32x16& s1)
+{
+    if (blk == 0) {
+        s0 = m1 + m2;            // output 2
+        s1 = m1 - m2;            // output 3
+        k0 = m0 + s0;            // output 0
+        k1 = s1;                 // output 1
+    } else {
+        s0 = m0 + m1;            // output 0
+        f32x16 df = m0 - m1;
+        s1 = df * 2.f;           // output 1
+        k0 = s0 * 4.f;           // output 2
+        k1 = df * 8.f + m2;      // output 3
+    }
+}
+
+template <int LVL>
+__global__ __launch_bounds__(512, 1)
+void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2all, int64_t h2_step_stride,
+                           const float* __restrict__ params, IflStepList steps, IflStepOff off, IflXGeom g, int ngroups, int ncombo)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * XTBUF];          // V[0], V[1], T[0], T[1]
+    // Workgroup -> (network, step, tile group).  A workgroup streams its network's whole transformed filter bank (2.95 MB per
+    // step) and every workgroup of a (network, step) pair streams the same one, so the pairs are dealt to the 8 XCDs
+    // (linear workgroup id % 8): each XCD works through all tile groups of ONE pair at a time and keeps that pair's
+    // weights in its 4 MB L2, instead of several pairs evicting each other.
+    int grp, combo;
+    {
+        const int id = blockIdx.x;
+        if ((ncombo & 7) == 0) { const int t = id >> 3; grp = t % ngroups; combo = (t / ngroups) * 8 + (id & 7); }
+        else { grp = id % ngroups; combo = id / ngroups; }
+    }
+    const int step = combo >> 1, net = combo & 1;
+    const float* prm = params + steps.off[step];
+    float* h2P = h2all + (int64_t)step * h2_step_stride;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int mh = wave >> 2, bi = (wave >> 1) & 1, bj = wave & 1;        // waves w and w + 4 (same block, other half) share a SIMD
+    const bool xf = wave < 6;                                              // transform waves
+    const int tpi = g.TH * g.TW;
+    const int plane = g.HP * g.WP * IFL_XCH;  // floats per (image, sub-chunk)
+    const int rowp = g.WP * IFL_XCH;
+
+    // ---- pass-1 role: (tile t1, window column c, quad q): 12 lanes cover a window row's 192 bytes ------------------------
+    unsigned p1_src;
+    int p1_dst;
+    {
+        const int t1 = tid / 12, rem = tid - t1 * 12, c = rem >> 1, q = rem & 1;
+        int gt = grp * 32 + (t1 < 32 ? t1 : 31);
+        if (gt >= g.ntiles) gt = g.ntiles - 1;
+        const int b = gt / tpi, r2 = gt - b * tpi;
+        const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
+        p1_src = ((b * XN * g.HP + 4 * tr) * g.WP + 4 * tc + c) * IFL_XCH + 4 * q;
+        p1_dst = c * XTROW + t1 * 8 + 4 * (q ^ ((t1 >> 3) & 1));          // + i * 6 * XTROW
+    }
+    // ---- pass-2 role: row i = wave, (tile, quad) = (j, h); same LDS pattern as the GEMM's reads ------------------------------
+    const int swz = j * 8 + 4 * (h ^ ((j >> 3) & 1));
+    const int p2_row = wave * 6;
+    // ---- GEMM role ---------------------------------------------------------------------------------------------------------
+    const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + swz;                  // V[(3 bi + il) * 6 + 3 bj + jl][j][h]: + (il * 6 + jl) * 256
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // weights: [half][block][sub-chunk][position][lane][4], contiguous per wave; the ring's last loads run past the wave's
+    // region into the next one / the pad behind the field
+    const float* wp = prm + off.w1x[net] + (int64_t)(mh * 4 + bi * 2 + bj) * (XN * 9 * 256);       // wave-uniform
+    const unsigned wl = lane * 4;
+    f32x4 wq[XRD];
+#pragma unroll
+    for (int k = 0; k < XRD; ++k) wq[k] = *(const f32x4*)(wp + k * 256 + wl);
+
+    f32x4 d[6];
+    auto load_window = [&](int s) {
+        const float* src = ftp + s * plane;   // uniform base + 32-bit lane offset
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = *(const f32x4*)(src + r * rowp + p1_src);
+    };
+    auto pass1 = [&](float* T) {              // d -> T[i][c][tile][quad]
+        bt6([&](int r) { return d[r]; }, [&](int i, f32x4 v) { *(f32x4*)(T + p1_dst + i * (6 * XTROW)) = v; });
+    };
+    auto pass2 = [&](const float* T, float* V) {
+        bt6([&](int c) { return *(const f32x4*)(T + (p2_row + c) * XTROW + swz); },
+            [&](int jc, f32x4 v) { *(f32x4*)(V + (p2_row + jc) * 256 + swz) = v; });
+    };
+
+    // ---- prologue: V[0] and T[1] ready, window of sub-chunk 2 in flight ---------------------------------------------------------
+    if (xf) {
+        load_window(0);
+        pass1(lds + 2 * XBUF);
+        load_window(1);
+    }
+    __syncthreads();
+    if (xf) {
+        pass2(lds + 2 * XBUF, lds);
+        pass1(lds + 2 * XBUF + XTBUF);
+        load_window(2);
+    }
+
+    auto sub_chunk = [&](int s, auto par) {
+        constexpr int PAR = decltype(par)::value;
+        const float* vr = lds + PAR * XBUF + vrd;
+        __syncthreads();                      // V[PAR] and T[PAR ^ 1] complete; V[PAR ^ 1] and T[PAR] free
+        const float* wc = wp + (int64_t)s * (9 * 256);
+        f32x4 xb[2][2];
+        xb[0][0] = *(const f32x4*)(vr);
+        xb[0][1] = *(const f32x4*)(vr + 256);
+#pragma unroll
+        for (int pp = 0; pp < 5; ++pp) {      // position pairs (0,1) (2,3) (4,5) (6,7) and 8 alone
+            const int p0 = 2 * pp, np = pp < 4 ? 2 : 1;
+            if (pp < 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = p0 + 2 + u;
+                    if (p < 9) xb[(pp + 1) & 1][u] = *(const f32x4*)(vr + ((p / 3) * 6 + p % 3) * 256);
+                }
+            }
+            // the window registers are dead between pass 1 and the next loads: pass 2's temporaries use that gap
+            if (pp == 0 && xf && s + 2 < XN) pass1(lds + 2 * XBUF + PAR * XTBUF);
+            if (pp == 1 && xf && s + 1 < XN) pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF);
+            if (pp == 2 && xf && s + 3 < XN) load_window(s + 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < np; ++u)
+                    acc[p0 + u] = mfma32(wq[(PAR * 9 + p0 + u) % XRD][e], xb[pp & 1][u][e], acc[p0 + u]);
+#pragma unroll
+            for (int u = 0; u < np; ++u)
+                wq[(PAR * 9 + p0 + u) % XRD] = *(const f32x4*)(wc + (p0 + u + XRD) * 256 + wl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s < XN; s += 2) {
+        sub_chunk(s, std::integral_constant<int, 0>{});
+        sub_chunk(s + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- output transform ----------------------------------------------------------------------------------------------------
+    // stage 1 along i (partner: other bi = wave ^ 2), in two rounds (jl = 0,1 then jl = 2: 32 + 16 slots of 4 KB)
+    f32x16 P[2][3];
+    {
+        float* mine = lds + wave * (4 * XSLOT) + lane * 4;
+        const float* theirs = lds + (wave ^ 2) * (4 * XSLOT) + lane * 4;
+        __syncthreads();                      // every wave's GEMM reads of V are over
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) {
+            f32x16 s0, s1;
+            at_part(bi, acc[jl], acc[3 + jl], acc[6 + jl], P[0][jl], P[1][jl], s0, s1);
+            st16(mine + jl * XSLOT, s0);
+            st16(mine + (2 + jl) * XSLOT, s1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) add16(theirs + (dy * 2 + jl) * XSLOT, P[dy][jl]);
+        __syncthreads();
+        {
+            f32x16 s0, s1;
+            at_part(bi, acc[2], acc[5], acc[8], P[0][2], P[1][2], s0, s1);
+            st16(mine, s0);
+            st16(mine + XSLOT, s1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) add16(theirs + dy * XSLOT, P[dy][2]);
+    }
+    // stage 2 along jc (partner: other bj = wave ^ 1)
+    f32x16 Y[2][2];
+    {
+        float* mine = lds + wave * (4 * XSLOT) + lane * 4;
+        const float* theirs = lds + (wave ^ 1) * (4 * XSLOT) + lane * 4;
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            f32x16 s0, s1;
+            at_part(bj, P[dy][0], P[dy][1], P[dy][2], Y[dy][0], Y[dy][1], s0, s1);
+            st16(mine + (dy * 2) * XSLOT, s0);
+            st16(mine + (dy * 2 + 1) * XSLOT, s1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) add16(theirs + (dy * 2 + dx) * XSLOT, Y[dy][dx]);
+    }
+
+    // ---- this lane's tile and output pixels ------------------------------------------------------------------------------------
+    int64_t pix00 = -1;                       // ring pixel index of the tile's pixel (0, 0), or -1
+    int ty = 0, tx = 0;
+    {
+        int gt = grp * 32 + j;
+        if (gt < g.ntiles) {
+            const int b = gt / tpi, r2 = gt - b * tpi;
+            const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
+            ty = 4 * tr; tx = 4 * tc;
+            pix00 = ((int64_t)b * (g.H + 2) + ty + 1) * (g.W + 2) + tx + 1;
+        }
+    }
+    auto out_pix = [&](int dy, int dx) -> int64_t {
+        return (pix00 >= 0 && ty + dy < g.H && tx + dx < g.W) ? pix00 + dy * (g.W + 2) + dx : -1;
+    };
+
+    if (net == 0) {
+        // fAffine: raw sums of this wave's 32 channels, finished by conv1_finish_kernel once z1 of the step exists
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int64_t op = out_pix(2 * bi + dy, 2 * bj + dx);
+                if (op < 0) continue;
+                float* dst = h2P + op * IFL_H2 + mh * 32 + 4 * h;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(f32x4*)(dst + gq * 8) = f32x4{Y[dy][dx][gq * 4], Y[dy][dx][gq * 4 + 1], Y[dy][dx][gq * 4 + 2], Y[dy][dx][gq * 4 + 3]};
+            }
+    } else {
+        // fFeatures: half mh keeps pixel row dy = mh of the block and takes the other half's channels of it (partner wave ^ 4)
+        f32x16 a2[2][2];
+        float* mine = lds + wave * (2 * XSLOT) + lane * 4;
+        const float* theirs = lds + (wave ^ 4) * (2 * XSLOT) + lane * 4;
+        __syncthreads();
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) st16(mine + dx * XSLOT, Y[mh ^ 1][dx]);
+        __syncthreads();
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            ld16(theirs + dx * XSLOT, a2[mh ^ 1][dx]);
+            a2[mh][dx] = Y[mh][dx];
+        }
+        int64_t opix[2];
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) opix[dx] = out_pix(2 * bi + mh, 2 * bj + dx);
+        finish_and_store<2, IFL_H2>(a2, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
+    }
+}
+
+}  // namespace
+
+int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st)
+{
+    if (nsteps <= 0) return 0;
+    const IflXGeom g = ifl_xgeom(B, H, W);
+    if (ifl_ftp_floats(B, H, W) >= (int64_t)1 << 31) {
+        ifl_set_error("conv1_ft (Winograd 4x4): conditioning slab of %d x %d x %d exceeds 2^31 floats", B, H, W);
+        return IFL_ENOTSUP;
+    }
+    const int ngroups = (g.ntiles + 31) / 32, ncombo = 2 * nsteps;
+    if ((int64_t)ngroups * ncombo >= (int64_t)1 << 31) {
+        ifl_set_error("conv1_ft (Winograd 4x4): %d tile groups x %d exceed the grid", ngroups, ncombo);
+        return IFL_ENOTSUP;
+    }
+    dim3 grid(ngroups * ncombo), block(512);
+    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino4_kernel<1>, grid, block, 0, st, ftp, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
+    else hipLaunchKernelGGL(conv1_ft_wino4_kernel<2>, grid, block, 0, st, ftp, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

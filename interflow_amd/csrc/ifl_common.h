@@ -67,6 +67,7 @@ struct IflStepOff {       // float offsets inside one step's block
     int64_t w1[2], an1[2], w2[2], an2[2], w3[2], b3[2];     // [0] = fAffine, [1] = fFeatures
     int64_t w1b[2], w2b;      // bf16 copies for the bf16 variant of conv1_ft: first conv over ft (both nets), fFeatures' 1x1
     int64_t w1w[2];           // Winograd F(2x2,3x3) transforms U = G g G^T of the conditioning part of the first conv (both nets)
+    int64_t w1x[2];           // Winograd F(4x4,3x3) transforms (6x6 domain) of the same weights
     int64_t total;
 };
 
@@ -92,7 +93,9 @@ static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_couplin
         take(4096);                                                // pad: the weight prefetch ring reads past a field's end
         for (int n = 0; n < 2; ++n) o.w1w[n] = take((int64_t)16 * IFL_HID * IFL_FT);
         take(4096);
-    } else { o.w1b[0] = o.w1b[1] = o.w2b = o.w1w[0] = o.w1w[1] = 0; }
+        for (int n = 0; n < 2; ++n) o.w1x[n] = take((int64_t)36 * IFL_HID * IFL_FT);
+        take(4096);
+    } else { o.w1b[0] = o.w1b[1] = o.w2b = o.w1w[0] = o.w1w[1] = o.w1x[0] = o.w1x[1] = 0; }
     o.total = p;
     return o;
 }
@@ -104,6 +107,21 @@ static inline IflWGeom ifl_wgeom(int B, int H, int W) {
     IflWGeom g; g.H = H; g.W = W; g.TH = (H + 1) / 2; g.TW = (W + 1) / 2; g.ntiles = B * g.TH * g.TW; return g;
 }
 
+// ---- Winograd F(4x4,3x3) tiling: 4x4-pixel output tiles in raster order over (image, tile row, tile column), 32 consecutive
+// tiles per workgroup.  The kernel reads the conditioning features from a second copy in "planar-8" layout
+// [B][40 chunks of 8 channels][HP][WP][8]: a zero ring like the channels-last copy, zero-padded up to whole tiles
+// (HP = 4 TH + 2, WP = 4 TW + 2), so a tile's 6x6 input window needs no bound tests and a window row of one chunk is
+// 192 contiguous bytes. -------------------------------------------------------------------------------------------------------
+#define IFL_XCH 8             // channels per chunk of the planar copy
+struct IflXGeom { int H, W, TH, TW, ntiles, HP, WP; };      // ntiles = B * TH * TW
+static inline __host__ __device__ IflXGeom ifl_xgeom(int B, int H, int W) {
+    IflXGeom g; g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4; g.ntiles = B * g.TH * g.TW;
+    g.HP = 4 * g.TH + 2; g.WP = 4 * g.TW + 2; return g;
+}
+static inline int64_t ifl_ftp_floats(int B, int H, int W) {
+    IflXGeom g = ifl_xgeom(B, H, W); return (int64_t)B * (IFL_FT / IFL_XCH) * g.HP * g.WP * IFL_XCH;
+}
+
 #define IFL_MAX_COND 16       // conditional steps per level (flow_model.py:42 K=16)
 struct IflStepList { int64_t off[IFL_MAX_COND]; };     // float offsets of the steps' parameter blocks
 
@@ -112,6 +130,7 @@ struct IflLevelWs {
     int H, W;                 // plane size at this level
     int C;                    // z channels
     float* ft;                // [B][H+2][W+2][320]  zero ring
+    float* ftp;               // [B][40][HP][WP][8]  planar-8 copy of the same features (IflXGeom), zero ring and padding
     float* z;                 // [B][H+2][W+2][C]    zero ring
     float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step: [0:64] fAffine's
                               //   conditioning-only pre-activation sums, [64:128] fFeatures' finished hidden activations
@@ -161,6 +180,7 @@ void ifl_set_error(const char* fmt, ...);
 // layout.hip
 int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);                 // NCHW -> ringed NHWC
 int ifl_k_ring_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);
+int ifl_k_nchw_to_planar8(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);             // NCHW -> [B][C/8][HP][WP][8]
 int ifl_k_squeeze_in(const float* x, float* zr, int B, int C, int H, int W, hipStream_t st);                     // NCHW [B,C,H,W] -> ringed NHWC [B,H/2,W/2,4C]
 int ifl_k_unsqueeze_out(const float* zr, float* x, int B, int C, int H, int W, hipStream_t st);                  // inverse
 int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hipStream_t st);                    // ringed [H,W,C] -> ringed [H/2,W/2,4C]
@@ -181,6 +201,9 @@ int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const 
                    int nsteps, const IflStepOff& off, const IflGeom& g, int B, int level, int bf16, hipStream_t st);
 int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
+// conv1x.hip
+int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (fAffine's conv, both couplings), 2 = decode (fAffine's conv and coupling)

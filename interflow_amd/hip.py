@@ -21,7 +21,8 @@ FLOW_BF16_CONV1 = 2
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
- F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16, F_W1A_WINO, F_W1F_WINO) = range(19)
+ F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16, F_W1A_WINO, F_W1F_WINO,
+ F_W1A_WINO4, F_W1F_WINO4) = range(21)
 
 
 class IflLayer(Structure):
@@ -131,7 +132,7 @@ def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -
     check(lib().ifl_set_schedule(aux_stream, groups, p1_chunk_steps), "ifl_set_schedule")
 
 
-CONV1_DIRECT, CONV1_WINOGRAD = 0, 1
+CONV1_DIRECT, CONV1_WINOGRAD, CONV1_WINOGRAD4 = 0, 1, 2
 
 
 def set_conv1_algo(algo: int = -1) -> int:

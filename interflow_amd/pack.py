@@ -72,6 +72,20 @@ def _pack_conv1_wino(wt, zoff):
     return np.ascontiguousarray(u.transpose(7, 2, 3, 6, 0, 4, 1, 5)).reshape(-1)
 
 
+_WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                     [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], np.float64)
+
+
+def _pack_conv1_wino4(wt, zoff):
+    """Conditioning part of wt [64, Cin, 3, 3] -> Winograd F(4x4,3x3) domain U = G g G^T (6x6, float64, rounded once to
+    fp32), laid out [mh][bi][bj][s][il][jl][hh][o][e]: position (3 bi + il, 3 bj + jl), out channel mh*32 + o, in channel
+    s*8 + hh*4 + e (conv1x.hip, conv1_ft_wino4_kernel: contiguous per wave, MFMA A-fragment order)."""
+    g = wt[:, zoff:zoff + N_RRDB_CH].astype(np.float64)                          # [64, 320, 3, 3]
+    u = np.einsum("ia,ocab,jb->ocij", _WINO4_G, g, _WINO4_G).astype(F32)         # [64, 320, 6, 6]
+    u = u.reshape(2, 32, 40, 2, 4, 2, 3, 2, 3)                                   # mh o s hh e bi il bj jl
+    return np.ascontiguousarray(u.transpose(0, 5, 7, 2, 6, 8, 3, 1, 4)).reshape(-1)
+
+
 def to_bf16_bits(a):
     """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)."""
     u = np.ascontiguousarray(a, F32).view(np.uint32)
@@ -184,6 +198,8 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
                 _pack_conv1_bf16(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
             put(hip.F_W1A_WINO if net == 0 else hip.F_W1F_WINO,
                 _pack_conv1_wino(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
+            put(hip.F_W1A_WINO4 if net == 0 else hip.F_W1F_WINO4,
+                _pack_conv1_wino4(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
             if net == 1:
                 put(hip.F_W2F_BF16, _pack_conv2_bf16(prm[q + "2.weight"].astype(F32)))
     return float(np.sum(logs, dtype=F32)), float(sum_log_s)

@@ -160,7 +160,7 @@ def test_full160_golden(golden_dir, sd_np, model):
     print(f"full160 rel errs: z {e1:.2e} logdet {e2:.2e} x {e3:.2e} logdet_rev {e4:.2e}")
 
 
-@pytest.mark.parametrize("algo", [hip.CONV1_DIRECT, hip.CONV1_WINOGRAD])
+@pytest.mark.parametrize("algo", [hip.CONV1_DIRECT, hip.CONV1_WINOGRAD, hip.CONV1_WINOGRAD4])
 def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
     """Both forms of the bulk convolution (direct implicit GEMM, Winograd F(2x2,3x3)) meet the tolerance against the
     reference's outputs on the 160x160 fixture, on an image whose deeper planes have odd sizes (20x36 -> 5x9: the

@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): rocprofv3 timing profile of the default bench.py command plus the PMC passes
 # (one counter block per run, as rocprofv3 does not split passes), each condensed by tools/prof_summary.py into a
 # small CSV under gpurun_out/<tag>/ -- copy the ones to keep into profiles/.
-#   usage: bash tools/gpu_profile.sh <tag> [bench args for the PMC passes]
+#   usage: [SKIP_STATS=1] bash tools/gpu_profile.sh <tag> [bench args for the PMC passes]
 set -o pipefail
 TAG=${1:-prof}
 shift
@@ -11,9 +11,9 @@ export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p "$O"
 
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d "$O/raw_stats" -- python3 bench.py --no-cpu-baseline > "$O/stats.log" 2>&1 \
+[ -n "$SKIP_STATS" ] || { timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d "$O/raw_stats" -- python3 bench.py --no-cpu-baseline > "$O/stats.log" 2>&1 \
   && python3 tools/prof_summary.py "$O/raw_stats" "$O/kernel_stats.csv" --rm || { tail -20 "$O/stats.log"; exit 1; }
-grep '^{' "$O/stats.log" > "$O/bench_under_rocprof.json"
+grep '^{' "$O/stats.log" > "$O/bench_under_rocprof.json"; }
 
 pass() {   # name, counters...
   local name=$1; shift
