@@ -353,7 +353,7 @@ int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params
     float* h2 = lv.h2 + (int64_t)s0 * lv.h2_step;
     int rc;
     { ProfScope ps(level == 1 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-      if (!bf16 && conv1_algo() == 2)
+      if (!bf16 && conv1_algo() == 2 && ifl_ftp_floats(w.B, lv.H, lv.W) < (int64_t)1 << 30)      // 32-bit byte offsets; larger slabs use F(2x2)
           rc = ifl_k_conv1_ft_wino4(lv.ftp, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
       else if (!bf16 && conv1_algo() == 1)
           rc = ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);

@@ -16,14 +16,13 @@
 // The 320 input channels are walked in 40 sub-chunks of 8.  Per sub-chunk s, between two barriers:
 //   GEMM(s)      every wave: its 9 positions x 4 k-steps on V[s & 1] (one 16-byte LDS read per position), weights streamed
 //                global -> VGPR through a 6-deep ring (fragment order, contiguous per wave);
-//   pass 2(s+1)  waves 0-5: T[(s+1) & 1] -> V[(s+1) & 1], the transform along the window's columns (item = tile, row i, quad);
+//   pass 2(s+1)  waves 2-7: T[(s+1) & 1] -> V[(s+1) & 1], the transform along the window's columns (item = tile, row i, quad);
 //   pass 1(s+2)  waves 0-5: registers -> T[s & 1], the transform along the window's rows (item = tile, column c, quad) of the
 //                6 window pixels loaded one sub-chunk earlier; then the loads for sub-chunk s + 3.
 // The features are read from the planar-8 copy (ifl_common.h, IflXGeom): the 12 lanes of a tile cover the 192 contiguous
 // bytes of a window row, and zero padding up to whole tiles removes every bound test.
-// LDS: V and T double-buffered, each [36 positions][32 tiles][8 channels] (T rows 32 bytes apart more) -> 149,760 B.  A row's
-// two 16-byte quads are swapped for tiles 8-15 and 24-31, which makes the 16-byte reads bank-conflict free without
-// padding the tiles; the T row pitch does the same for the pass-1 stores.
+// LDS: V and T double-buffered, each [36 positions][2 quads][32 tiles][4 channels] (T's quads 16 bytes further apart)
+// -> 149,760 B: the 16-byte reads of a wave and the 8-lane groups of its 16-byte stores fall into distinct banks.
 // Epilogue: the output transform A^T M A is linear, so each wave reduces its 3x3 block to partial sums and exchanges them
 // with its partner block through LDS, first along i, then along jc; afterwards wave (bi, bj) holds output pixels
 // (2 bi + {0,1}, 2 bj + {0,1}) of its 32 tiles and 32 channels in the usual accumulator layout.  fAffine's raw sums are stored
@@ -37,10 +36,11 @@ namespace {
 
 constexpr int XN = IFL_FT / IFL_XCH;          // 40 sub-chunks
 constexpr int XBUF = 36 * 32 * IFL_XCH;       // floats per V buffer
-constexpr int XTROW = 32 * IFL_XCH + 8;       // floats per (i, c) row of T: 8 more than it holds, so that the four columns a
+constexpr int XTQ = 32 * 4 + 4;               // floats per (row, quad) of T and
+constexpr int XTROW = 2 * XTQ;                // per (i, c) row: a little more than they hold, so that the columns and quads one
                                               // pass-1 store instruction covers fall into different banks
 constexpr int XTBUF = 36 * XTROW;
-constexpr int XRD = 6;                        // weight ring depth (positions)
+constexpr int XRD = 9;                        // weight ring depth (positions)
 constexpr int XSLOT = 16 * 64;                // floats per exchanged f32x16 (all lanes)
 
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 y) {
@@ -113,6 +113,19 @@ __device__ __forceinline__ void at_part(int blk, const f32x16& m0, const f32x16&
     }
 }
 
+// Build with -DIFL_EXP_TIME (tools/build_exp.sh) to record per-wave timestamps (tools/exp_x4_timeline.py); never defined in
+// the product build.
+#ifdef IFL_EXP_TIME
+__device__ unsigned long long ifl_dbgx[8192 * 8 * 8];
+#define XT_STAMP(k) do { if (LVL == 1 && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
+#define XT_PUT(k, v) do { if (LVL == 1 && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = (v); } while (0)
+#define XT_CLK() clock64()
+#else
+#define XT_STAMP(k) do {} while (0)
+#define XT_PUT(k, v) do {} while (0)
+#define XT_CLK() 0ll
+#endif
+
 template <int LVL>
 __global__ __launch_bounds__(512, 1)
 void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2all, int64_t h2_step_stride,
@@ -137,7 +150,8 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
     const int mh = wave >> 2, bi = (wave >> 1) & 1, bj = wave & 1;        // waves w and w + 4 (same block, other half) share a SIMD
-    const bool xf = wave < 6;                                              // transform waves
+    const bool xf1 = wave < 6, xf2 = wave >= 2;                            // pass-1 waves (item = tid), pass-2 waves (row i = wave - 2)
+    const bool late = wave >= 4;                                           // waves w and w + 4 share a SIMD: they transform at different times
     const int tpi = g.TH * g.TW;
     const int plane = g.HP * g.WP * IFL_XCH;  // floats per (image, sub-chunk)
     const int rowp = g.WP * IFL_XCH;
@@ -151,14 +165,14 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
         if (gt >= g.ntiles) gt = g.ntiles - 1;
         const int b = gt / tpi, r2 = gt - b * tpi;
         const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
-        p1_src = ((b * XN * g.HP + 4 * tr) * g.WP + 4 * tc + c) * IFL_XCH + 4 * q;
-        p1_dst = c * XTROW + t1 * 8 + 4 * (q ^ ((t1 >> 3) & 1));          // + i * 6 * XTROW
+        p1_src = (((b * XN * g.HP + 4 * tr) * g.WP + 4 * tc + c) * IFL_XCH + 4 * q) * 4u;          // bytes (< 2^32: checked by the launcher)
+        p1_dst = c * XTROW + q * XTQ + t1 * 4;          // + i * 6 * XTROW
     }
     // ---- pass-2 role: row i = wave, (tile, quad) = (j, h); same LDS pattern as the GEMM's reads ------------------------------
-    const int swz = j * 8 + 4 * (h ^ ((j >> 3) & 1));
-    const int p2_row = wave * 6;
+    const int vlo = h * 128 + j * 4, tlo = h * XTQ + j * 4;               // V[pos][quad][tile][4], T[i * 6 + c][quad][tile][4]
+    const int p2_row = ((wave - 2) & 7) * 6;
     // ---- GEMM role ---------------------------------------------------------------------------------------------------------
-    const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + swz;                  // V[(3 bi + il) * 6 + 3 bj + jl][j][h]: + (il * 6 + jl) * 256
+    const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + vlo;                  // V[(3 bi + il) * 6 + 3 bj + jl][j][h]: + (il * 6 + jl) * 256
 
     f32x16 acc[9];
 #pragma unroll
@@ -169,34 +183,49 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     // weights: [half][block][sub-chunk][position][lane][4], contiguous per wave; the ring's last loads run past the wave's
     // region into the next one / the pad behind the field
     const float* wp = prm + off.w1x[net] + (int64_t)(mh * 4 + bi * 2 + bj) * (XN * 9 * 256);       // wave-uniform
-    const unsigned wl = lane * 4;
+    const unsigned wl = lane * 16;            // bytes
     f32x4 wq[XRD];
 #pragma unroll
-    for (int k = 0; k < XRD; ++k) wq[k] = *(const f32x4*)(wp + k * 256 + wl);
+    for (int k = 0; k < XRD; ++k) wq[k] = *(const f32x4*)((const char*)(wp + k * 256) + wl);
 
     f32x4 d[6];
-    auto load_window = [&](int s) {
-        const float* src = ftp + s * plane;   // uniform base + 32-bit lane offset
+#ifdef IFL_EXP_NOWIN
 #pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = *(const f32x4*)(src + r * rowp + p1_src);
+    for (int r = 0; r < 6; ++r) d[r] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(tid + r);
+#endif
+    auto load_window = [&](int s) {
+#ifdef IFL_EXP_NOWIN
+        return;
+#endif
+        const float* src = ftp + s * plane;   // uniform base + 32-bit lane offset in bytes: one address register for all rows
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = *(const f32x4*)((const char*)(src + r * rowp) + p1_src);
     };
     auto pass1 = [&](float* T) {              // d -> T[i][c][tile][quad]
+#ifdef IFL_EXP_NOPASS
+        return;
+#endif
         bt6([&](int r) { return d[r]; }, [&](int i, f32x4 v) { *(f32x4*)(T + p1_dst + i * (6 * XTROW)) = v; });
     };
     auto pass2 = [&](const float* T, float* V) {
-        bt6([&](int c) { return *(const f32x4*)(T + (p2_row + c) * XTROW + swz); },
-            [&](int jc, f32x4 v) { *(f32x4*)(V + (p2_row + jc) * 256 + swz) = v; });
+#ifdef IFL_EXP_NOPASS
+        return;
+#endif
+        bt6([&](int c) { return *(const f32x4*)(T + (p2_row + c) * XTROW + tlo); },
+            [&](int jc, f32x4 v) { *(f32x4*)(V + (p2_row + jc) * 256 + vlo) = v; });
     };
 
+    XT_STAMP(0);
+    long long xt_bar = 0, xt_pass = 0;
     // ---- prologue: V[0] and T[1] ready, window of sub-chunk 2 in flight ---------------------------------------------------------
-    if (xf) {
+    if (xf1) {
         load_window(0);
         pass1(lds + 2 * XBUF);
         load_window(1);
     }
     __syncthreads();
-    if (xf) {
-        pass2(lds + 2 * XBUF, lds);
+    if (xf2) pass2(lds + 2 * XBUF, lds);
+    if (xf1) {
         pass1(lds + 2 * XBUF + XTBUF);
         load_window(2);
     }
@@ -204,40 +233,58 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     auto sub_chunk = [&](int s, auto par) {
         constexpr int PAR = decltype(par)::value;
         const float* vr = lds + PAR * XBUF + vrd;
+        { long long c0 = XT_CLK();
         __syncthreads();                      // V[PAR] and T[PAR ^ 1] complete; V[PAR ^ 1] and T[PAR] free
+        xt_bar += XT_CLK() - c0; }
         const float* wc = wp + (int64_t)s * (9 * 256);
-        f32x4 xb[2][2];
-        xb[0][0] = *(const f32x4*)(vr);
-        xb[0][1] = *(const f32x4*)(vr + 256);
+        f32x4 xb[2];                          // one pair of positions at a time: read right after the previous pair's MFMAs are issued
+        xb[0] = *(const f32x4*)(vr);
+        xb[1] = *(const f32x4*)(vr + 256);
 #pragma unroll
         for (int pp = 0; pp < 5; ++pp) {      // position pairs (0,1) (2,3) (4,5) (6,7) and 8 alone
             const int p0 = 2 * pp, np = pp < 4 ? 2 : 1;
-            if (pp < 4) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int p = p0 + 2 + u;
-                    if (p < 9) xb[(pp + 1) & 1][u] = *(const f32x4*)(vr + ((p / 3) * 6 + p % 3) * 256);
-                }
+            // Pass 1 (waves 0-5), pass 2 (waves 2-7), next loads; the window registers are dead between pass 1 and the loads, and
+            // pass 2's temporaries use that gap.  The two waves of a SIMD do this at different points of the sub-chunk.
+            if (pp == 0 && !late) {
+                if (xf1 && s + 2 < XN) { long long c0 = XT_CLK(); pass1(lds + 2 * XBUF + PAR * XTBUF); xt_pass += XT_CLK() - c0; }
             }
-            // the window registers are dead between pass 1 and the next loads: pass 2's temporaries use that gap
-            if (pp == 0 && xf && s + 2 < XN) pass1(lds + 2 * XBUF + PAR * XTBUF);
-            if (pp == 1 && xf && s + 1 < XN) pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF);
-            if (pp == 2 && xf && s + 3 < XN) load_window(s + 3);
+            if (pp == 1 && !late) {
+                if (xf2 && s + 1 < XN) { long long c0 = XT_CLK(); pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF); xt_pass += XT_CLK() - c0; }
+                if (xf1 && s + 3 < XN) load_window(s + 3);
+            }
+            if (pp == 2 && late) {
+                if (xf1 && s + 2 < XN) { long long c0 = XT_CLK(); pass1(lds + 2 * XBUF + PAR * XTBUF); xt_pass += XT_CLK() - c0; }
+            }
+            if (pp == 3 && late) {
+                if (s + 1 < XN) { long long c0 = XT_CLK(); pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF); xt_pass += XT_CLK() - c0; }
+                if (xf1 && s + 3 < XN) load_window(s + 3);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int u = 0; u < np; ++u)
-                    acc[p0 + u] = mfma32(wq[(PAR * 9 + p0 + u) % XRD][e], xb[pp & 1][u][e], acc[p0 + u]);
+                    acc[p0 + u] = mfma32(wq[(PAR * 9 + p0 + u) % XRD][e], xb[u][e], acc[p0 + u]);
 #pragma unroll
             for (int u = 0; u < np; ++u)
-                wq[(PAR * 9 + p0 + u) % XRD] = *(const f32x4*)(wc + (p0 + u + XRD) * 256 + wl);
+                wq[(PAR * 9 + p0 + u) % XRD] = *(const f32x4*)((const char*)(wc + (p0 + u + XRD) * 256) + wl);
+            if (pp < 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = p0 + 2 + u;
+                    if (p < 9) xb[u] = *(const f32x4*)(vr + ((p / 3) * 6 + p % 3) * 256);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    XT_STAMP(1);
+    const long long xt_c1 = XT_CLK();
     for (int s = 0; s < XN; s += 2) {
         sub_chunk(s, std::integral_constant<int, 0>{});
         sub_chunk(s + 1, std::integral_constant<int, 1>{});
     }
+    XT_PUT(5, (unsigned long long)xt_bar); XT_PUT(6, (unsigned long long)(XT_CLK() - xt_c1)); XT_PUT(7, (unsigned long long)xt_pass);
+    XT_STAMP(2);
 
     // ---- output transform ----------------------------------------------------------------------------------------------------
     // stage 1 along i (partner: other bi = wave ^ 2), in two rounds (jl = 0,1 then jl = 2: 32 + 16 slots of 4 KB)
@@ -245,27 +292,28 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     {
         float* mine = lds + wave * (4 * XSLOT) + lane * 4;
         const float* theirs = lds + (wave ^ 2) * (4 * XSLOT) + lane * 4;
-        __syncthreads();                      // every wave's GEMM reads of V are over
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);                      // every wave's GEMM reads of V are over
 #pragma unroll
         for (int jl = 0; jl < 2; ++jl) {
             f32x16 s0, s1;
             at_part(bi, acc[jl], acc[3 + jl], acc[6 + jl], P[0][jl], P[1][jl], s0, s1);
             st16(mine + jl * XSLOT, s0);
             st16(mine + (2 + jl) * XSLOT, s1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the partial sums of one column at a time in registers
         }
-        __syncthreads();
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) add16(theirs + (dy * 2 + jl) * XSLOT, P[dy][jl]);
-        __syncthreads();
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);
         {
             f32x16 s0, s1;
             at_part(bi, acc[2], acc[5], acc[8], P[0][2], P[1][2], s0, s1);
             st16(mine, s0);
             st16(mine + XSLOT, s1);
         }
-        __syncthreads();
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) add16(theirs + dy * XSLOT, P[dy][2]);
     }
@@ -274,21 +322,23 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     {
         float* mine = lds + wave * (4 * XSLOT) + lane * 4;
         const float* theirs = lds + (wave ^ 1) * (4 * XSLOT) + lane * 4;
-        __syncthreads();
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             f32x16 s0, s1;
             at_part(bj, P[dy][0], P[dy][1], P[dy][2], Y[dy][0], Y[dy][1], s0, s1);
             st16(mine + (dy * 2) * XSLOT, s0);
             st16(mine + (dy * 2 + 1) * XSLOT, s1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) add16(theirs + (dy * 2 + dx) * XSLOT, Y[dy][dx]);
     }
 
+    XT_STAMP(3);
     // ---- this lane's tile and output pixels ------------------------------------------------------------------------------------
     int64_t pix00 = -1;                       // ring pixel index of the tile's pixel (0, 0), or -1
     int ty = 0, tx = 0;
@@ -320,23 +370,29 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
             }
     } else {
         // fFeatures: half mh keeps pixel row dy = mh of the block and takes the other half's channels of it (partner wave ^ 4)
-        f32x16 a2[2][2];
         float* mine = lds + wave * (2 * XSLOT) + lane * 4;
         const float* theirs = lds + (wave ^ 4) * (2 * XSLOT) + lane * 4;
-        __syncthreads();
+        // (compile-time indices only: a register array indexed by the runtime `mh` would be placed in scratch memory)
+        auto finish_half = [&](auto mhc) {
+            constexpr int MH = decltype(mhc)::value;
+            __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) st16(mine + dx * XSLOT, Y[mh ^ 1][dx]);
-        __syncthreads();
+            for (int dx = 0; dx < 2; ++dx) st16(mine + dx * XSLOT, Y[MH ^ 1][dx]);
+            __syncthreads(); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            ld16(theirs + dx * XSLOT, a2[mh ^ 1][dx]);
-            a2[mh][dx] = Y[mh][dx];
-        }
-        int64_t opix[2];
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) opix[dx] = out_pix(2 * bi + mh, 2 * bj + dx);
-        finish_and_store<2, IFL_H2>(a2, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
+            for (int dx = 0; dx < 2; ++dx) {  // one pixel set at a time keeps the 1x1 conv's operands and results in registers
+                f32x16 a1[2][1];
+                ld16(theirs + dx * XSLOT, a1[MH ^ 1][0]);
+                a1[MH][0] = Y[MH][dx];
+                int64_t opix[1] = {out_pix(2 * bi + MH, 2 * bj + dx)};
+                finish_and_store<1, IFL_H2>(a1, prm + off.an1[1], prm + off.w2[1], prm + off.an2[1], h2P + IFL_HID, opix, lane, h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (mh == 0) finish_half(std::integral_constant<int, 0>{});
+        else finish_half(std::integral_constant<int, 1>{});
     }
+    XT_STAMP(4);
 }
 
 }  // namespace
@@ -346,8 +402,8 @@ int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride,
 {
     if (nsteps <= 0) return 0;
     const IflXGeom g = ifl_xgeom(B, H, W);
-    if (ifl_ftp_floats(B, H, W) >= (int64_t)1 << 31) {
-        ifl_set_error("conv1_ft (Winograd 4x4): conditioning slab of %d x %d x %d exceeds 2^31 floats", B, H, W);
+    if (ifl_ftp_floats(B, H, W) >= (int64_t)1 << 30) {
+        ifl_set_error("conv1_ft (Winograd 4x4): conditioning slab of %d x %d x %d exceeds 2^32 bytes", B, H, W);
         return IFL_ENOTSUP;
     }
     const int ngroups = (g.ntiles + 31) / 32, ncombo = 2 * nsteps;
@@ -361,3 +417,7 @@ int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride,
     IFL_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef IFL_EXP_TIME
+extern "C" int ifl_dbgx_read(void* host, size_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ifl_dbgx), bytes); }
+#endif

@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinterflow_hip.so")
+LIB_PATH = os.environ.get("IFL_LIB_PATH") or os.path.join(_HERE, "libinterflow_hip.so")     # IFL_LIB_PATH: experiment builds (tools/build_exp.sh)
 
 IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
 FLOW_COND_PREPARED = 1
