@@ -197,15 +197,18 @@ def main():
         # dominant kernel: the level-1 (C=12, 80x80 planes) instantiation of the bulk kernel: the conditioning part of both
         # coupling networks' first conv (+ fFeatures' 1x1).  Work per conditional step and pixel in the direct form
         # SURVEY.md section 8(a) row a11 counts (without the z1 taps, fAffine's 1x1 and the last conv):
-        # 2 x 64*9*320 + 64*64 MACs.  The Winograd F(2x2,3x3) form (default) issues 16 instead of 36 multiplications per
-        # 2x2 outputs and filter tap set, i.e. 2 x 64*4*320 + 64*64 MACs per pixel on the matrix cores (its data / output
-        # transforms are additions on the vector ALUs and are not counted).
-        wino = hip.set_conv1_algo(-1) == hip.CONV1_WINOGRAD
-        kname = "conv1_ft_wino_kernel<1>" if wino else "conv1_ft_kernel<1>"
+        # 2 x 64*9*320 + 64*64 MACs.  The Winograd F(4x4,3x3) form (default) issues 36 multiplications per 4x4 outputs, input
+        # and output channel instead of 144, i.e. 2 x 64*2.25*320 + 64*64 MACs per pixel on the matrix cores (F(2x2,3x3): 16
+        # per 2x2 outputs, 2 x 64*4*320 + 64*64); the data / output transforms run on the vector ALUs and are not counted.
+        algo = hip.set_conv1_algo(-1)
+        wino = algo != hip.CONV1_DIRECT
+        kname = {hip.CONV1_DIRECT: "conv1_ft_kernel<1>", hip.CONV1_WINOGRAD: "conv1_ft_wino_kernel<1>",
+                 hip.CONV1_WINOGRAD4: "conv1_ft_wino4_kernel<1>"}[algo]
         ms1, n1 = dom_ms, dom_n
         px1 = (PATCH // 2) ** 2
         macs_px_direct = 2 * 64 * 9 * 320 + 64 * 64
-        macs_px = (2 * 64 * 4 * 320 + 64 * 64) if wino else macs_px_direct
+        macs_px = {hip.CONV1_DIRECT: macs_px_direct, hip.CONV1_WINOGRAD: 2 * 64 * 4 * 320 + 64 * 64,
+                   hip.CONV1_WINOGRAD4: 2 * 64 * 9 * 320 // 4 + 64 * 64}[algo]
         per_mac = 2.0 * px1 * B * 16 * 2 * args.steps                   # 16 conditional steps, encode + decode
         flops_total, flops_total_direct = per_mac * macs_px, per_mac * macs_px_direct
         flops_launch = flops_total / max(n1, 1)
@@ -230,9 +233,11 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": kname + " (both coupling networks' first 3x3 conv over the 320 conditioning "
                                    "channels + fFeatures' 1x1, level 1, %d conditional steps per launch)" % round(32 * args.steps / max(n1, 1)),
-                         "algorithm": ("Winograd F(2x2,3x3) minimal filtering in fp32: achieved/frac count the multiply-adds "
-                                       "the kernel issues on the matrix cores (16 per 2x2 outputs instead of the direct form's "
-                                       "36); direct_equivalent_tflops prices the same launch at the direct-form FLOPs of "
+                         "algorithm": (("Winograd F(4x4,3x3)" if algo == hip.CONV1_WINOGRAD4 else "Winograd F(2x2,3x3)") +
+                                       " minimal filtering in fp32: achieved/frac count the multiply-adds the kernel issues on "
+                                       "the matrix cores (" + ("36 per 4x4 outputs instead of the direct form's 144" if algo == hip.CONV1_WINOGRAD4
+                                                               else "16 per 2x2 outputs instead of the direct form's 36") +
+                                       "); direct_equivalent_tflops prices the same launch at the direct-form FLOPs of "
                                        "SURVEY.md section 8(d) and may exceed the hardware peak") if wino else "direct implicit GEMM",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,

@@ -136,7 +136,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.C = 3 << (2 * (l + 1));
         int64_t ring = (int64_t)B * (lv.H + 2) * (lv.W + 2);
         lv.ft = take(ring * IFL_FT);
-        lv.ftp = take(ifl_ftp_floats(B, lv.H, lv.W));
+        lv.vg = take(ifl_vg_floats(B, lv.H, lv.W));
         lv.z = take(ring * lv.C);
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
@@ -161,7 +161,7 @@ static int check_shape(int B, int H, int W, int div = 4)
 {
     IFL_CHECK_ARG(B >= 1 && H >= div && W >= div, IFL_EINVAL, "bad shape B=%d H=%d W=%d", B, H, W);
     IFL_CHECK_ARG(H % div == 0 && W % div == 0, IFL_EINVAL, "H=%d, W=%d must be multiples of %d (flow.py:172)", H, W, div);
-    IFL_CHECK_ARG((int64_t)(H / 2 + 6) * (W / 2 + 6) * IFL_FT < (int64_t)1 << 31, IFL_ENOTSUP,
+    IFL_CHECK_ARG((int64_t)(H / 2 + 2) * (W / 2 + 2) * IFL_FT < (int64_t)1 << 31, IFL_ENOTSUP,
                   "image plane too large for 32-bit tile offsets: tile the image");
     IFL_CHECK_ARG(B <= 65535, IFL_ENOTSUP, "B=%d exceeds the grid's y extent", B);
     return 0;
@@ -188,13 +188,13 @@ extern "C" int ifl_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, void
     return 0;
 }
 
-// both copies of a level's conditioning features: ringed channels-last (direct, F(2x2) and bf16 kernels, training) and
-// planar-8 (F(4x4) kernel)
+// a level's conditioning features in both forms: ringed channels-last (direct, F(2x2) and bf16 kernels, training) and the
+// Winograd F(4x4,3x3) input transform of every tile (conv1x.hip), computed from the ringed copy
 static int load_ft(const IflLevelWs& lv, int B, const float* ft_nchw, hipStream_t st)
 {
     int rc = ifl_k_nchw_to_ring(ft_nchw, lv.ft, B, IFL_FT, lv.H, lv.W, st);
     if (rc) return rc;
-    return ifl_k_nchw_to_planar8(ft_nchw, lv.ftp, B, IFL_FT, lv.H, lv.W, st);
+    return ifl_k_wino4_input(lv.ft, lv.vg, B, lv.H, lv.W, st);
 }
 
 extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const float* ft_nchw, void* stream)
@@ -288,7 +288,8 @@ static int check_layers(const ifl_layer* layers, int n_layers)
 // own stream, forked from and joined back to the caller's stream with events.
 // The auxiliary streams and events are created once per device on first use and kept for the life of the process.
 #define IFL_MAX_GROUPS 4
-#define IFL_P1_CHUNK 8
+#define IFL_P1_CHUNK 4         // level 1: 4 steps x 2 networks = one (network, step) pair per XCD and launch (conv1x.hip)
+#define IFL_P1_CHUNK_L2 8
 namespace {
 int env_int(const char* name, int dflt);
 constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
@@ -333,7 +334,7 @@ struct Sched { int aux, groups, chunk, chunk2; };      // chunk: level-1 steps p
 Sched& sched()
 {
     static Sched s{env_int("IFL_AUX_STREAM", 1), env_int("IFL_GROUPS", 2), env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK),
-                   env_int("IFL_P1_CHUNK_STEPS_L2", IFL_P1_CHUNK)};
+                   env_int("IFL_P1_CHUNK_STEPS_L2", IFL_P1_CHUNK_L2)};
     return s;
 }
 
@@ -353,8 +354,8 @@ int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params
     float* h2 = lv.h2 + (int64_t)s0 * lv.h2_step;
     int rc;
     { ProfScope ps(level == 1 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-      if (!bf16 && conv1_algo() == 2 && ifl_ftp_floats(w.B, lv.H, lv.W) < (int64_t)1 << 30)      // 32-bit byte offsets; larger slabs use F(2x2)
-          rc = ifl_k_conv1_ft_wino4(lv.ftp, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
+      if (!bf16 && conv1_algo() == 2)
+          rc = ifl_k_conv1_ft_wino4(lv.vg, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
       else if (!bf16 && conv1_algo() == 1)
           rc = ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
       else

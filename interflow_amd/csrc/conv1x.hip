@@ -11,18 +11,19 @@
 //   M[co][tile] = U[co][ci] V[ci][tile]     (fp32 throughout; the result differs from the direct form by fp32 rounding only:
 //                                            tools/exp_wino_error.py, tests/test_gpu_parity.py).
 //
-// Workgroup = one network x 32 consecutive tiles (raster order over image, tile row, tile column) = 512 output pixels x 64
-// channels; 8 waves = 2 halves of the output channels x 4 blocks of 3x3 positions, 144 accumulator registers per wave.
-// The 320 input channels are walked in 40 sub-chunks of 8.  Per sub-chunk s, between two barriers:
-//   GEMM(s)      every wave: its 9 positions x 4 k-steps on V[s & 1] (one 16-byte LDS read per position), weights streamed
-//                global -> VGPR through a 6-deep ring (fragment order, contiguous per wave);
-//   pass 2(s+1)  waves 2-7: T[(s+1) & 1] -> V[(s+1) & 1], the transform along the window's columns (item = tile, row i, quad);
-//   pass 1(s+2)  waves 0-5: registers -> T[s & 1], the transform along the window's rows (item = tile, column c, quad) of the
-//                6 window pixels loaded one sub-chunk earlier; then the loads for sub-chunk s + 3.
-// The features are read from the planar-8 copy (ifl_common.h, IflXGeom): the 12 lanes of a tile cover the 192 contiguous
-// bytes of a window row, and zero padding up to whole tiles removes every bound test.
-// LDS: V and T double-buffered, each [36 positions][2 quads][32 tiles][4 channels] (T's quads 16 bytes further apart)
-// -> 149,760 B: the 16-byte reads of a wave and the 8-lane groups of its 16-byte stores fall into distinct banks.
+// Two kernels:
+//   wino4_input_kernel     V = B^T d B of every tile and channel, once per loaded conditioning map (ifl_load_cond): ringed
+//                          channels-last features -> vg[tile group][sub-chunk of 8 channels][position][quad][tile][4], i.e. per
+//                          (group of 32 tiles, sub-chunk) the 36,864-byte LDS image the GEMM kernel multiplies.  HBM-bound.
+//                          Every (network, step) of every launch reuses it: 32 uses per pass.
+//   conv1_ft_wino4_kernel  workgroup = one network x one step x 32 consecutive tiles (raster order over image, tile row, tile
+//                          column) = 512 output pixels x 64 channels; 8 waves = 2 halves of the output channels x 4 blocks of
+//                          3x3 positions, 144 accumulator registers per wave.  The 320 input channels are walked in 40
+//                          sub-chunks of 8; per sub-chunk, between two barriers, every wave multiplies its 9 positions x 4
+//                          k-steps on V[s & 1] (one 16-byte LDS read per position; weights streamed global -> VGPR through a
+//                          9-deep ring, fragment order, contiguous per wave), stores the image of sub-chunk s + 1 (loaded one
+//                          sub-chunk earlier, 4.5 x 16 bytes per thread) into V[(s + 1) & 1] and loads that of s + 2.
+// LDS image [36 positions][2 quads][32 tiles][4 channels]: the 16-byte reads of a wave fall into distinct banks.
 // Epilogue: the output transform A^T M A is linear, so each wave reduces its 3x3 block to partial sums and exchanges them
 // with its partner block through LDS, first along i, then along jc; afterwards wave (bi, bj) holds output pixels
 // (2 bi + {0,1}, 2 bj + {0,1}) of its 32 tiles and 32 channels in the usual accumulator layout.  fAffine's raw sums are stored
@@ -35,11 +36,8 @@ namespace {
 #include "conv1_fin.h"
 
 constexpr int XN = IFL_FT / IFL_XCH;          // 40 sub-chunks
-constexpr int XBUF = 36 * 32 * IFL_XCH;       // floats per V buffer
-constexpr int XTQ = 32 * 4 + 4;               // floats per (row, quad) of T and
-constexpr int XTROW = 2 * XTQ;                // per (i, c) row: a little more than they hold, so that the columns and quads one
-                                              // pass-1 store instruction covers fall into different banks
-constexpr int XTBUF = 36 * XTROW;
+constexpr int XBUF = 36 * 32 * IFL_XCH;       // floats per V image (one tile group, one sub-chunk)
+constexpr int XLDS = 8 * 4 * 16 * 64;         // LDS floats: the epilogue's exchange (8 waves x 4 x f32x16 per lane) > two V images
 constexpr int XRD = 9;                        // weight ring depth (positions)
 constexpr int XSLOT = 16 * 64;                // floats per exchanged f32x16 (all lanes)
 
@@ -126,16 +124,46 @@ __device__ unsigned long long ifl_dbgx[8192 * 8 * 8];
 #define XT_CLK() 0ll
 #endif
 
+// ---- input transform: ringed channels-last features -> Winograd-domain images -------------------------------------------
+// Thread = (tile of the group, quad of channels); block = 32 tiles x 8 quads (4 sub-chunks); grid (groups, 10).  Loads: 8 lanes
+// cover a pixel's 128 contiguous bytes; stores: the 32 tiles of a (position, quad) are 512 contiguous bytes.  Window pixels
+// beyond the ringed plane (tiles overhanging a plane whose size is not a multiple of 4) and tiles past the last one are zeros.
+__global__ __launch_bounds__(256)
+void wino4_input_kernel(const float* __restrict__ ftP, float* __restrict__ vg, IflXGeom g)
+{
+    const int grp = blockIdx.x, sb = blockIdx.y;
+    const int tid = threadIdx.x, t = tid >> 3, q8 = tid & 7;
+    const int tpi = g.TH * g.TW, W2 = g.W + 2;
+    int gt = grp * 32 + t;
+    const bool live = gt < g.ntiles;
+    if (!live) gt = g.ntiles - 1;
+    const int b = gt / tpi, r2 = gt - b * tpi;
+    const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
+    const float* src = ftP + ((int64_t)(b * (g.H + 2) + 4 * tr) * W2 + 4 * tc) * IFL_FT + sb * 32 + q8 * 4;
+    f32x4 T[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const bool cin = live && 4 * tc + c <= g.W + 1;
+        bt6([&](int r) { return (cin && 4 * tr + r <= g.H + 1) ? *(const f32x4*)(src + (int64_t)(r * W2 + c) * IFL_FT) : f32x4{0.f, 0.f, 0.f, 0.f}; },
+            [&](int i, f32x4 v) { T[i][c] = v; });
+    }
+    float* dst = vg + ((int64_t)(grp * XN + sb * 4 + (q8 >> 1)) * 36) * 256 + (q8 & 1) * 128 + t * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        bt6([&](int c) { return T[i][c]; }, [&](int jc, f32x4 v) { *(f32x4*)(dst + (i * 6 + jc) * 256) = v; });
+}
+
 template <int LVL>
 __global__ __launch_bounds__(512, 1)
-void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2all, int64_t h2_step_stride,
+void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2all, int64_t h2_step_stride,
                            const float* __restrict__ params, IflStepList steps, IflStepOff off, IflXGeom g, int ngroups, int ncombo)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * XTBUF];          // V[0], V[1], T[0], T[1]
+    __shared__ __attribute__((aligned(16))) float lds[XLDS];              // V[0], V[1]; the epilogue's exchange slots
     // Workgroup -> (network, step, tile group).  A workgroup streams its network's whole transformed filter bank (2.95 MB per
     // step) and every workgroup of a (network, step) pair streams the same one, so the pairs are dealt to the 8 XCDs
     // (linear workgroup id % 8): each XCD works through all tile groups of ONE pair at a time and keeps that pair's
-    // weights in its 4 MB L2, instead of several pairs evicting each other.
+    // weights in its 4 MB L2, instead of several pairs evicting each other.  The XCDs walk the tile groups in step, so a
+    // group's images are fetched from HBM once and served to the other XCDs by the Infinity Cache.
     int grp, combo;
     {
         const int id = blockIdx.x;
@@ -150,29 +178,8 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
     const int mh = wave >> 2, bi = (wave >> 1) & 1, bj = wave & 1;        // waves w and w + 4 (same block, other half) share a SIMD
-    const bool xf1 = wave < 6, xf2 = wave >= 2;                            // pass-1 waves (item = tid), pass-2 waves (row i = wave - 2)
-    const bool late = wave >= 4;                                           // waves w and w + 4 share a SIMD: they transform at different times
     const int tpi = g.TH * g.TW;
-    const int plane = g.HP * g.WP * IFL_XCH;  // floats per (image, sub-chunk)
-    const int rowp = g.WP * IFL_XCH;
-
-    // ---- pass-1 role: (tile t1, window column c, quad q): 12 lanes cover a window row's 192 bytes ------------------------
-    unsigned p1_src;
-    int p1_dst;
-    {
-        const int t1 = tid / 12, rem = tid - t1 * 12, c = rem >> 1, q = rem & 1;
-        int gt = grp * 32 + (t1 < 32 ? t1 : 31);
-        if (gt >= g.ntiles) gt = g.ntiles - 1;
-        const int b = gt / tpi, r2 = gt - b * tpi;
-        const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
-        p1_src = (((b * XN * g.HP + 4 * tr) * g.WP + 4 * tc + c) * IFL_XCH + 4 * q) * 4u;          // bytes (< 2^32: checked by the launcher)
-        p1_dst = c * XTROW + q * XTQ + t1 * 4;          // + i * 6 * XTROW
-    }
-    // ---- pass-2 role: row i = wave, (tile, quad) = (j, h); same LDS pattern as the GEMM's reads ------------------------------
-    const int vlo = h * 128 + j * 4, tlo = h * XTQ + j * 4;               // V[pos][quad][tile][4], T[i * 6 + c][quad][tile][4]
-    const int p2_row = ((wave - 2) & 7) * 6;
-    // ---- GEMM role ---------------------------------------------------------------------------------------------------------
-    const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + vlo;                  // V[(3 bi + il) * 6 + 3 bj + jl][j][h]: + (il * 6 + jl) * 256
+    const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + h * 128 + j * 4;      // V[(3 bi + il) * 6 + 3 bj + jl][quad h][tile j]: + (il * 6 + jl) * 256
 
     f32x16 acc[9];
 #pragma unroll
@@ -188,77 +195,53 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
 #pragma unroll
     for (int k = 0; k < XRD; ++k) wq[k] = *(const f32x4*)((const char*)(wp + k * 256) + wl);
 
-    f32x4 d[6];
+    // image staging: 2304 16-byte pieces per sub-chunk, piece tid + 512 k for k = 0..4 (k = 4: waves 0-3 only)
+    const float* vgrp = vg + (int64_t)grp * (XN * XBUF);                   // uniform
+    const unsigned vl = tid * 16;             // bytes
+    const bool five = wave < 4;
+    f32x4 sv[5];
+    auto load_v = [&](int s) {
+#ifdef IFL_EXP_NOWIN
+        return;
+#endif
+        const char* src = (const char*)(vgrp + s * XBUF);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)(src + k * 8192 + vl);
+        if (five) sv[4] = *(const f32x4*)(src + 4 * 8192 + vl);
+    };
+    auto store_v = [&](float* V) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)((char*)V + k * 8192 + vl) = sv[k];
+        if (five) *(f32x4*)((char*)V + 4 * 8192 + vl) = sv[4];
+    };
 #ifdef IFL_EXP_NOWIN
 #pragma unroll
-    for (int r = 0; r < 6; ++r) d[r] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(tid + r);
+    for (int k = 0; k < 5; ++k) sv[k] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(tid + k);
 #endif
-    auto load_window = [&](int s) {
-#ifdef IFL_EXP_NOWIN
-        return;
-#endif
-        const float* src = ftp + s * plane;   // uniform base + 32-bit lane offset in bytes: one address register for all rows
-#pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = *(const f32x4*)((const char*)(src + r * rowp) + p1_src);
-    };
-    auto pass1 = [&](float* T) {              // d -> T[i][c][tile][quad]
-#ifdef IFL_EXP_NOPASS
-        return;
-#endif
-        bt6([&](int r) { return d[r]; }, [&](int i, f32x4 v) { *(f32x4*)(T + p1_dst + i * (6 * XTROW)) = v; });
-    };
-    auto pass2 = [&](const float* T, float* V) {
-#ifdef IFL_EXP_NOPASS
-        return;
-#endif
-        bt6([&](int c) { return *(const f32x4*)(T + (p2_row + c) * XTROW + tlo); },
-            [&](int jc, f32x4 v) { *(f32x4*)(V + (p2_row + jc) * 256 + vlo) = v; });
-    };
 
     XT_STAMP(0);
     long long xt_bar = 0, xt_pass = 0;
-    // ---- prologue: V[0] and T[1] ready, window of sub-chunk 2 in flight ---------------------------------------------------------
-    if (xf1) {
-        load_window(0);
-        pass1(lds + 2 * XBUF);
-        load_window(1);
-    }
-    __syncthreads();
-    if (xf2) pass2(lds + 2 * XBUF, lds);
-    if (xf1) {
-        pass1(lds + 2 * XBUF + XTBUF);
-        load_window(2);
-    }
+    load_v(0);
+    store_v(lds);
+    load_v(1);
 
     auto sub_chunk = [&](int s, auto par) {
         constexpr int PAR = decltype(par)::value;
         const float* vr = lds + PAR * XBUF + vrd;
         { long long c0 = XT_CLK();
-        __syncthreads();                      // V[PAR] and T[PAR ^ 1] complete; V[PAR ^ 1] and T[PAR] free
+        __syncthreads();                      // V[PAR] complete; V[PAR ^ 1] free
         xt_bar += XT_CLK() - c0; }
         const float* wc = wp + (int64_t)s * (9 * 256);
         f32x4 xb[2];                          // one pair of positions at a time: read right after the previous pair's MFMAs are issued
         xb[0] = *(const f32x4*)(vr);
         xb[1] = *(const f32x4*)(vr + 256);
+        { long long c0 = XT_CLK();
+        if (s + 1 < XN) store_v(lds + (PAR ^ 1) * XBUF);
+        if (s + 2 < XN) load_v(s + 2);
+        xt_pass += XT_CLK() - c0; }
 #pragma unroll
         for (int pp = 0; pp < 5; ++pp) {      // position pairs (0,1) (2,3) (4,5) (6,7) and 8 alone
             const int p0 = 2 * pp, np = pp < 4 ? 2 : 1;
-            // Pass 1 (waves 0-5), pass 2 (waves 2-7), next loads; the window registers are dead between pass 1 and the loads, and
-            // pass 2's temporaries use that gap.  The two waves of a SIMD do this at different points of the sub-chunk.
-            if (pp == 0 && !late) {
-                if (xf1 && s + 2 < XN) { long long c0 = XT_CLK(); pass1(lds + 2 * XBUF + PAR * XTBUF); xt_pass += XT_CLK() - c0; }
-            }
-            if (pp == 1 && !late) {
-                if (xf2 && s + 1 < XN) { long long c0 = XT_CLK(); pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF); xt_pass += XT_CLK() - c0; }
-                if (xf1 && s + 3 < XN) load_window(s + 3);
-            }
-            if (pp == 2 && late) {
-                if (xf1 && s + 2 < XN) { long long c0 = XT_CLK(); pass1(lds + 2 * XBUF + PAR * XTBUF); xt_pass += XT_CLK() - c0; }
-            }
-            if (pp == 3 && late) {
-                if (s + 1 < XN) { long long c0 = XT_CLK(); pass2(lds + 2 * XBUF + (PAR ^ 1) * XTBUF, lds + (PAR ^ 1) * XBUF); xt_pass += XT_CLK() - c0; }
-                if (xf1 && s + 3 < XN) load_window(s + 3);
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -397,23 +380,28 @@ void conv1_ft_wino4_kernel(const float* __restrict__ ftp, float* __restrict__ h2
 
 }  // namespace
 
-int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipStream_t st)
+{
+    const IflXGeom g = ifl_xgeom(B, H, W);
+    dim3 grid((g.ntiles + 31) / 32, XN / 4), block(256);
+    hipLaunchKernelGGL(wino4_input_kernel, grid, block, 0, st, ft_ring, vg, g);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                          int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st)
 {
     if (nsteps <= 0) return 0;
     const IflXGeom g = ifl_xgeom(B, H, W);
-    if (ifl_ftp_floats(B, H, W) >= (int64_t)1 << 30) {
-        ifl_set_error("conv1_ft (Winograd 4x4): conditioning slab of %d x %d x %d exceeds 2^32 bytes", B, H, W);
-        return IFL_ENOTSUP;
-    }
     const int ngroups = (g.ntiles + 31) / 32, ncombo = 2 * nsteps;
     if ((int64_t)ngroups * ncombo >= (int64_t)1 << 31) {
         ifl_set_error("conv1_ft (Winograd 4x4): %d tile groups x %d exceed the grid", ngroups, ncombo);
         return IFL_ENOTSUP;
     }
     dim3 grid(ngroups * ncombo), block(512);
-    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino4_kernel<1>, grid, block, 0, st, ftp, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
-    else hipLaunchKernelGGL(conv1_ft_wino4_kernel<2>, grid, block, 0, st, ftp, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
+    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino4_kernel<1>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
+    else hipLaunchKernelGGL(conv1_ft_wino4_kernel<2>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
     IFL_LAUNCH_CHECK();
     return 0;
 }

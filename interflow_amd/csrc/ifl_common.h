@@ -108,18 +108,16 @@ static inline IflWGeom ifl_wgeom(int B, int H, int W) {
 }
 
 // ---- Winograd F(4x4,3x3) tiling: 4x4-pixel output tiles in raster order over (image, tile row, tile column), 32 consecutive
-// tiles per workgroup.  The kernel reads the conditioning features from a second copy in "planar-8" layout
-// [B][40 chunks of 8 channels][HP][WP][8]: a zero ring like the channels-last copy, zero-padded up to whole tiles
-// (HP = 4 TH + 2, WP = 4 TW + 2), so a tile's 6x6 input window needs no bound tests and a window row of one chunk is
-// 192 contiguous bytes. -------------------------------------------------------------------------------------------------------
-#define IFL_XCH 8             // channels per chunk of the planar copy
-struct IflXGeom { int H, W, TH, TW, ntiles, HP, WP; };      // ntiles = B * TH * TW
+// tiles per workgroup.  The GEMM kernel reads the conditioning features already transformed (V = B^T d B per tile and
+// channel), as one 36,864-byte LDS image per (group of 32 tiles, sub-chunk of 8 channels):
+// vg[group][40 sub-chunks][36 positions][2 quads][32 tiles][4 channels] (conv1x.hip). ---------------------------------------
+#define IFL_XCH 8             // channels per sub-chunk
+struct IflXGeom { int H, W, TH, TW, ntiles; };      // ntiles = B * TH * TW
 static inline __host__ __device__ IflXGeom ifl_xgeom(int B, int H, int W) {
-    IflXGeom g; g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4; g.ntiles = B * g.TH * g.TW;
-    g.HP = 4 * g.TH + 2; g.WP = 4 * g.TW + 2; return g;
+    IflXGeom g; g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4; g.ntiles = B * g.TH * g.TW; return g;
 }
-static inline int64_t ifl_ftp_floats(int B, int H, int W) {
-    IflXGeom g = ifl_xgeom(B, H, W); return (int64_t)B * (IFL_FT / IFL_XCH) * g.HP * g.WP * IFL_XCH;
+static inline int64_t ifl_vg_floats(int B, int H, int W) {
+    IflXGeom g = ifl_xgeom(B, H, W); return (int64_t)((g.ntiles + 31) / 32) * (IFL_FT / IFL_XCH) * 36 * 32 * IFL_XCH;
 }
 
 #define IFL_MAX_COND 16       // conditional steps per level (flow_model.py:42 K=16)
@@ -130,7 +128,7 @@ struct IflLevelWs {
     int H, W;                 // plane size at this level
     int C;                    // z channels
     float* ft;                // [B][H+2][W+2][320]  zero ring
-    float* ftp;               // [B][40][HP][WP][8]  planar-8 copy of the same features (IflXGeom), zero ring and padding
+    float* vg;                // the same features in the Winograd F(4x4,3x3) domain (IflXGeom, conv1x.hip)
     float* z;                 // [B][H+2][W+2][C]    zero ring
     float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step: [0:64] fAffine's
                               //   conditioning-only pre-activation sums, [64:128] fFeatures' finished hidden activations
@@ -180,7 +178,6 @@ void ifl_set_error(const char* fmt, ...);
 // layout.hip
 int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);                 // NCHW -> ringed NHWC
 int ifl_k_ring_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);
-int ifl_k_nchw_to_planar8(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);             // NCHW -> [B][C/8][HP][WP][8]
 int ifl_k_squeeze_in(const float* x, float* zr, int B, int C, int H, int W, hipStream_t st);                     // NCHW [B,C,H,W] -> ringed NHWC [B,H/2,W/2,4C]
 int ifl_k_unsqueeze_out(const float* zr, float* x, int B, int C, int H, int W, hipStream_t st);                  // inverse
 int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hipStream_t st);                    // ringed [H,W,C] -> ringed [H/2,W/2,4C]
@@ -202,7 +199,8 @@ int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const 
 int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 // conv1x.hip
-int ifl_k_conv1_ft_wino4(const float* ftp, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
+int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipStream_t st);                    // ringed NHWC -> vg
+int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                          int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, hipStream_t st);

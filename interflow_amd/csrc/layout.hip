@@ -33,24 +33,6 @@ void nchw_to_ring_kernel(const float* __restrict__ in, float* __restrict__ out, 
     }
 }
 
-// ---- NCHW [B,C,H,W] -> planar-8 [B][C/8][HP][WP][8] with a zero ring and zero padding (IflXGeom, conv1x.hip) ------------
-// One thread per (pixel, chunk of 8 channels): 8 coalesced reads, 32 contiguous bytes written.
-__global__ __launch_bounds__(256)
-void nchw_to_planar8_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int HP, int WP)
-{
-    const int P = H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
-    if (p >= P) return;
-    const int y = p / W, x = p - y * W;
-    const float* src = in + ((int64_t)b * C + s * 8) * P + p;
-    f32x4 lo, hi;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { lo[k] = src[(int64_t)k * P]; hi[k] = src[(int64_t)(k + 4) * P]; }
-    float* dst = out + ((((int64_t)b * (C / 8) + s) * HP + y + 1) * WP + x + 1) * 8;
-    *(f32x4*)dst = lo;
-    *(f32x4*)(dst + 4) = hi;
-}
-
 __global__ __launch_bounds__(256)
 void ring_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W)
 {
@@ -222,15 +204,6 @@ int ifl_k_nchw_to_ring(const float* in, float* out, int B, int C, int H, int W, 
 {
     dim3 grid(ifl_cdiv(H * W, 32), ifl_cdiv(C, 32), B);
     hipLaunchKernelGGL(nchw_to_ring_kernel, grid, dim3(256), 0, st, in, out, C, H, W);
-    IFL_LAUNCH_CHECK();
-    return 0;
-}
-
-int ifl_k_nchw_to_planar8(const float* in, float* out, int B, int C, int H, int W, hipStream_t st)
-{
-    const IflXGeom g = ifl_xgeom(B, H, W);
-    dim3 grid(ifl_cdiv(H * W, 256), C / 8, B);
-    hipLaunchKernelGGL(nchw_to_planar8_kernel, grid, dim3(256), 0, st, in, out, C, H, W, g.HP, g.WP);
     IFL_LAUNCH_CHECK();
     return 0;
 }

@@ -33,7 +33,7 @@ for nname, sel in (("fAffine", net == 0), ("fFeatures", net == 1)):
         d = t[sel, w, :]
         loop_ns = np.median(ns(d[:, 2] - d[:, 1]))
         clk = np.median(d[:, 6])
-        print("%-9s wave %d  ns: prologue %6.0f  loop %7.0f  out-transform %6.0f  finish %6.0f  total %7.0f | loop clk %8.0f (%.2f GHz)  barrier-wait clk %7.0f (%.0f%%)  pass clk %7.0f (%.0f%%)" % (
+        print("%-9s wave %d  ns: prologue %6.0f  loop %7.0f  out-transform %6.0f  finish %6.0f  total %7.0f | loop clk %8.0f (%.2f GHz)  barrier-wait clk %7.0f (%.0f%%)  staging clk %7.0f (%.0f%%)" % (
             nname, w, np.median(ns(d[:, 1] - d[:, 0])), loop_ns, np.median(ns(d[:, 3] - d[:, 2])), np.median(ns(d[:, 4] - d[:, 3])),
             np.median(ns(d[:, 4] - d[:, 0])), clk, clk / loop_ns, np.median(d[:, 5]), 100 * np.median(d[:, 5] / d[:, 6]),
             np.median(d[:, 7]), 100 * np.median(d[:, 7] / d[:, 6])))

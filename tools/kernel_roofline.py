@@ -115,15 +115,17 @@ def main():
         both = lambda: (enc(), dec())
         px = {1: 6400, 2: 1600}
         size = "B=32 160x160, one pass"
-        for algo, macs, kn, note in ((hip.CONV1_WINOGRAD, 2 * 64 * 4 * 320 + 64 * 64, "conv1_ft_wino_kernel",
-                                      "Winograd F(2x2,3x3), default; MFMA multiply-adds issued"),
+        for algo, macs, kn, note in ((hip.CONV1_WINOGRAD4, 2 * 64 * 9 * 320 // 4 + 64 * 64, "conv1_ft_wino4_kernel",
+                                      "Winograd F(4x4,3x3), default; MFMA multiply-adds issued"),
+                                     (hip.CONV1_WINOGRAD, 2 * 64 * 4 * 320 + 64 * 64, "conv1_ft_wino_kernel",
+                                      "Winograd F(2x2,3x3); MFMA multiply-adds issued"),
                                      (hip.CONV1_DIRECT, 2 * 64 * 9 * 320 + 64 * 64, "conv1_ft_kernel", "direct implicit GEMM")):
             hip.set_conv1_algo(algo)
             for kid, lvl in ((hip.K_CONV1_FT_L1, 1), (hip.K_CONV1_FT_L2, 2)):
                 s, n = lib_time(kid, enc)
                 add(f"{kn}<{lvl}>", "first 3x3 conv of fFeatures+fAffine over ft, fFeatures 1x1 (flow.py:25-64); " + note,
                     "mfma", 2.0 * macs * px[lvl] * B * 16 / n, s, f"B=32, level {lvl}, {16 // n} steps per launch")
-        hip.set_conv1_algo(hip.CONV1_WINOGRAD)
+        hip.set_conv1_algo(hip.CONV1_WINOGRAD4)
         s, n = lib_time(hip.K_CONV1_FINISH, enc)
         flop = 2.0 * sum((64 * 9 * (C // 2) + 64 * 64) * px[l] for l, C in ((1, 12), (2, 48))) * B * 16 / n
         add("conv1_finish_kernel", "fAffine z1 taps + ActNorm/ReLU/1x1 (Ablation.py:228-233)", "mfma", flop, s,
