@@ -12,22 +12,29 @@
 
 namespace {
 
-// One thread per pixel of the ringed channels-last plane; W staged in LDS and read as broadcasts.
-template <int C>
+// SPLIT threads per pixel of the ringed channels-last plane (adjacent lanes), each producing C / SPLIT of the outputs from all
+// C inputs; W staged in LDS and read as broadcasts.  C = 48 uses 4 threads per pixel: 51 200 pixels per batch of 32 would
+// otherwise be less than one wave per SIMD, each with 2 304 dependent-issue FMAs.  In place: the lanes of a pixel sit in one
+// wave, whose loads all complete (they feed the arithmetic) before its stores issue.
+template <int C, int SPLIT>
 __global__ __launch_bounds__(256)
 void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse)
 {
+    constexpr int CO = C / SPLIT;
+    static_assert(CO % 4 == 0 && 256 % SPLIT == 0, "outputs per thread must be whole 16-byte words");
     __shared__ __attribute__((aligned(16))) float sw[C * C + 2 * C];
     for (int i = threadIdx.x; i < C * C + 2 * C; i += 256) sw[i] = prm[i];
     __syncthreads();
     const float* sb = sw;            // bias
     const float* ss = sw + C;        // exp(logs) or exp(-logs)
     const float* wm = sw + 2 * C;    // W[co][ci] row-major
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = t0 / SPLIT;
+    const int part = (int)(t0 - p * SPLIT);
     if (p >= (int64_t)B * H * W) return;
     int x = p % W; int64_t t = p / W; int y = t % H; int b = t / H;
     float* px = zr + (((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C;
-    float v[C], o[C];
+    float v[C], o[CO];
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
         f32x4 q = *(const f32x4*)(px + c);
@@ -37,12 +44,13 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
 #pragma unroll
         for (int c = 0; c < C; ++c) { v[c] = v[c] + sb[c]; v[c] = v[c] * ss[c]; }
     }
+    const int co0 = part * CO;
 #pragma unroll
-    for (int co = 0; co < C; ++co) {
+    for (int co = 0; co < CO; ++co) {
         float acc = 0.f;
 #pragma unroll
         for (int ci = 0; ci < C; ci += 4) {
-            f32x4 w = *(const f32x4*)(wm + co * C + ci);
+            f32x4 w = *(const f32x4*)(wm + (co0 + co) * C + ci);
             acc = fmaf(w[0], v[ci], acc); acc = fmaf(w[1], v[ci + 1], acc);
             acc = fmaf(w[2], v[ci + 2], acc); acc = fmaf(w[3], v[ci + 3], acc);
         }
@@ -50,10 +58,10 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
     }
     if (inverse) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { o[c] = o[c] * ss[c]; o[c] = o[c] - sb[c]; }
+        for (int c = 0; c < CO; ++c) { o[c] = o[c] * ss[co0 + c]; o[c] = o[c] - sb[co0 + c]; }
     }
 #pragma unroll
-    for (int c = 0; c < C; c += 4) *(f32x4*)(px + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
+    for (int c = 0; c < CO; c += 4) *(f32x4*)(px + co0 + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
 }
 
 __global__ __launch_bounds__(64)
@@ -155,9 +163,9 @@ void lerp_kernel(const float* __restrict__ za, const float* __restrict__ zb, con
 int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st)
 {
     int64_t n = (int64_t)B * H * W;
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (C == 12) hipLaunchKernelGGL((anic_kernel<12>), grid, block, 0, st, zr, prm, B, H, W, inverse);
-    else if (C == 48) hipLaunchKernelGGL((anic_kernel<48>), grid, block, 0, st, zr, prm, B, H, W, inverse);
+    dim3 block(256);
+    if (C == 12) hipLaunchKernelGGL((anic_kernel<12, 1>), dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
+    else if (C == 48) hipLaunchKernelGGL((anic_kernel<48, 4>), dim3((unsigned)((n * 4 + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
     else { ifl_set_error("actnorm+invconv: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();
     return 0;
