@@ -136,8 +136,8 @@ CONV1_DIRECT, CONV1_WINOGRAD, CONV1_WINOGRAD4 = 0, 1, 2
 
 
 def set_conv1_algo(algo: int = -1) -> int:
-    """Algorithm of the fp32 bulk convolution (ifl_set_conv1_algo): CONV1_WINOGRAD (default) or CONV1_DIRECT; any other
-    value only queries.  Returns the previous setting."""
+    """Algorithm of the fp32 bulk convolution (ifl_set_conv1_algo): CONV1_WINOGRAD4 (F(4x4,3x3), default), CONV1_WINOGRAD
+    (F(2x2,3x3)) or CONV1_DIRECT; any other value only queries.  Returns the previous setting."""
     return int(lib().ifl_set_conv1_algo(algo))
 
 
