@@ -64,6 +64,64 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
     for (int c = 0; c < CO; c += 4) *(f32x4*)(px + co0 + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
 }
 
+// C = 48 on the matrix cores (v_mfma_f32_16x16x4_f32): D[16 out x 16 px] += W[16 out x 4 in] X[4 in x 16 px].  A wave takes 64
+// pixels as four tiles of 16; lane (n = lane % 16, g = lane / 16) loads, for j = 0..2, the 16 bytes of pixel n at channels
+// 16 j + 4 g .. + 3 (the four lanes of a pixel cover 64 contiguous bytes per load), which are the B operands of k-steps
+// (j, e) with k = g; the matching A fragments W[16 t + n][16 j + 4 g + e] stay in 36 registers for the whole wave.  The
+// accumulator of tile t holds channels 16 t + 4 g + r of pixel n: one 16-byte store, and the same channel set as load j = t,
+// so one pair of ActNorm vectors per lane serves both directions.  No LDS.  In place: a pixel's four lanes sit in one wave.
+__device__ __forceinline__ f32x4 mfma16p(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(256)
+void anic48_mfma_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse)
+{
+    constexpr int C = 48;
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float* wm = prm + 2 * C;
+    f32x4 a[3][3], bb[3], sc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        bb[t] = *(const f32x4*)(prm + 16 * t + 4 * g);
+        sc[t] = *(const f32x4*)(prm + C + 16 * t + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[t][j] = *(const f32x4*)(wm + (16 * t + n) * C + 16 * j + 4 * g);
+    }
+    const int64_t total = (int64_t)B * H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int64_t p = p0 + pt * 16 + n;
+        const bool live = p < total;
+        const int64_t pc = live ? p : total - 1;
+        const int x = pc % W; const int64_t q = pc / W; const int y = q % H; const int b = q / H;
+        float* px = zr + (((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + 4 * g;
+        f32x4 v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = *(const f32x4*)(px + 16 * j);
+        if (!inverse) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[j] = v[j] + bb[j]; v[j] = v[j] * sc[j]; }
+        }
+        f32x4 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t] = mfma16p(a[t][j][e], v[j][e], acc[t]);
+        }
+        if (inverse) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { acc[t] = acc[t] * sc[t]; acc[t] = acc[t] - bb[t]; }
+        }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *(f32x4*)(px + 16 * t) = acc[t];
+        }
+    }
+}
+
 __global__ __launch_bounds__(64)
 void ld_finalize_kernel(const float* __restrict__ ldpart, int used, int ld_slots, const float* __restrict__ ld_in,
                         float* __restrict__ ld_out, double constant, double fsign, int fa0, int fan, int fb0, int fbn)
@@ -165,7 +223,7 @@ int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inve
     int64_t n = (int64_t)B * H * W;
     dim3 block(256);
     if (C == 12) hipLaunchKernelGGL((anic_kernel<12, 1>), dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
-    else if (C == 48) hipLaunchKernelGGL((anic_kernel<48, 4>), dim3((unsigned)((n * 4 + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
+    else if (C == 48) hipLaunchKernelGGL(anic48_mfma_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
     else { ifl_set_error("actnorm+invconv: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();
     return 0;
