@@ -627,6 +627,7 @@ void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
 // ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
 // 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
 // of 8 with zero weights).
+template <int KZ>
 __global__ __launch_bounds__(256, 2)
 void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__ h2P, float* __restrict__ haP,
                          const float* __restrict__ prm, IflStepOff off, IflGeom g, int C)
@@ -641,9 +642,8 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
     const int W2 = g.W + 2;
-    const int KZ = ifl_kz(C);
-    const int CSZ = KZ + 4;                   // 12 or 28 words: CSZ/4 odd => conflict-free b128 reads
-    const int nq = KZ / 4;
+    constexpr int CSZ = KZ + 4;               // 12 or 28 words: CSZ/4 odd => conflict-free b128 reads
+    constexpr int nq = KZ / 4;
 
     int a0[NT];
     int64_t opix[NT];
@@ -672,10 +672,11 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
     }
     __syncthreads();
     const float* wz = prm + off.w1[0] + (int64_t)NCC * (9 * 4 * 2 * 256) + lane * 4;
-    const int nkq = KZ / 8;
+    constexpr int nkq = KZ / 8;               // compile-time, so the whole tap loop unrolls and its weight loads are hoisted
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int tapoff = ((tap / 3) * t.PW + (tap % 3)) * (CSZ * 4);
+#pragma unroll
         for (int kq = 0; kq < nkq; ++kq) {
             f32x4 wa[2], xb[NT];
 #pragma unroll
@@ -737,7 +738,9 @@ int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* 
                        const IflGeom& g, int B, int C, hipStream_t st)
 {
     dim3 grid(g.ntiles, B), block(256);
-    hipLaunchKernelGGL(conv1_finish_kernel, grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    if (ifl_kz(C) == 8) hipLaunchKernelGGL(conv1_finish_kernel<8>, grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    else if (ifl_kz(C) == 24) hipLaunchKernelGGL(conv1_finish_kernel<24>, grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    else { ifl_set_error("conv1_finish: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();
     return 0;
 }

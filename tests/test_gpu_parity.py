@@ -122,6 +122,22 @@ def test_flow_step_oracle_ragged(sd, model, li, hw):
     rel_close(out, zw, what="dec z"); rel_close(ldo - ld.to(dev()), lw - ld, 2e-4, what="dec dlogdet")
 
 
+@pytest.mark.parametrize("C", [12, 48])
+def test_non_lu_invconv_step_golden(golden_dir, C):
+    """FlowStep with a plain (not LU-decomposed) 1x1 convolution, Permutations.py:78-86: the reference's outputs."""
+    from interflow_amd.flow_modules import FlowStep
+    g = dict(np.load(os.path.join(golden_dir, "nonlu_seed0.npz")))
+    step = FlowStep(in_channels=C, hidden_channels=64, flow_permutation="invconv", flow_coupling="noCoupling", LU_decomposed=False)
+    step.load_state_dict({k[len(f"c{C}."):]: t(v) for k, v in g.items()
+                          if k.startswith(f"c{C}.") and ("actnorm" in k or "invconv" in k)}, strict=True)
+    step.eval().to(dev())
+    z, ld = t(g[f"c{C}.z"]).to(dev()), t(g[f"c{C}.ld"]).to(dev())
+    zf, lf = step(z, ld, reverse=False)
+    rel_close(zf, g[f"c{C}.zf"], what="non-LU enc z"); rel_close(lf, g[f"c{C}.lf"], what="non-LU enc logdet")
+    zr, lr = step(t(g[f"c{C}.zf"]).to(dev()), t(g[f"c{C}.lf"]).to(dev()), reverse=True)
+    rel_close(zr, g[f"c{C}.zr"], what="non-LU dec z"); rel_close(lr, g[f"c{C}.lr"], 1e-3, what="non-LU dec logdet")
+
+
 # ----------------------------------------------------------------------------- whole stack
 def test_stack32_golden(golden_dir, sd_np, model):
     g = load(golden_dir, "stack32_seed0.npz", sd_np)

@@ -84,6 +84,19 @@ def test_step_ops(golden_dir, sd, tag):
     close(a, g[f"{tag}_step_dec"]); close(l, g[f"{tag}_step_dec_ld"], 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize("C", [12, 48])
+def test_non_lu_invconv_step(golden_dir, C):
+    """InvertibleConv1x1 without LU decomposition (Permutations.py:78-86): the reference's
+    FlowStep(noCoupling, LU_decomposed=False) outputs from tests/golden/make_golden_nonlu.py."""
+    g = _load(golden_dir, "nonlu_seed0.npz")
+    sdl = {k[len(f"c{C}."):]: t(v) for k, v in g.items() if k.startswith(f"c{C}.") and ("actnorm" in k or "invconv" in k)}
+    z, ld = t(g[f"c{C}.z"]), t(g[f"c{C}.ld"])
+    zf, lf = O.flow_step(z, ld, False, None, sdl, "")
+    close(zf, g[f"c{C}.zf"]); close(lf, g[f"c{C}.lf"], 1e-5, 1e-4)
+    zr, lr = O.flow_step(t(g[f"c{C}.zf"]), t(g[f"c{C}.lf"]), True, None, sdl, "")
+    close(zr, g[f"c{C}.zr"]); close(lr, g[f"c{C}.lr"], 1e-5, 1e-4)
+
+
 def test_gaussian_and_loss(golden_dir, sd):
     g = _load(golden_dir, "ops_seed0.npz")
     z = t(g["g_z"])
