@@ -217,7 +217,7 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
     int rc;
-    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, st); }
+    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, nullptr, st); }
     if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
@@ -234,8 +234,11 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     return 0;
 }
 
+// fapply_done: the previous kernel of the chain already applied this step's z = (z + shiftFt) * scaleFt; sf_next: apply the
+// next step's (the one the chain runs after this one) in this step's last kernel.
 static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
-                       int& slots, double& constant, float eps, hipStream_t st)
+                       int& slots, double& constant, float eps, hipStream_t st, bool fapply_done = false,
+                       const float* sf_next = nullptr)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
@@ -243,8 +246,10 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
     if (L.kind == 2) {
         const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
         const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
-        { ProfScope ps(IFL_K_CONV3_DEC, st); rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st); }
-        if (rc) return rc;
+        if (!fapply_done) {
+            ProfScope ps(IFL_K_CONV3_DEC, st);
+            if ((rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st))) return rc;
+        }
         { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
@@ -252,7 +257,7 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
         if (rc) return rc;
         slots += lv.geom.ntiles;
     }
-    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, st); }
+    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, sf_next, st); }
     if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant -= (double)L.sum_logs * px + (double)L.sum_log_s * px;
@@ -464,6 +469,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
         int lvl = IFL_MAX_LEVELS - 1;
         const IflLevelWs& last = w.lv[lvl];
         if ((rc = ifl_k_nchw_to_ring(src, last.z, B, last.C, last.H, last.W, st))) return rc;
+        bool fapply_done = false;
         for (int i = n_layers - 1; i >= 0; --i) {
             const ifl_layer& L = layers[i];
             if (L.kind == 0) {
@@ -473,7 +479,16 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
             } else {
                 const int slab = plan.slab_of_layer[i];
                 if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
-                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st);
+                // the layer the chain runs next, if it is a conditional step of the same level: its first half (fapply) is
+                // pointwise on the same pixels as this step's last kernel (ActNorm + 1x1 inverse), so it is fused into it
+                const float* sf_next = nullptr;
+                if (i > 0 && layers[i - 1].kind == 2) {
+                    const int nslab = plan.slab_of_layer[i - 1];
+                    if ((rc = wait_slab(lvl, nslab))) return rc;
+                    sf_next = w.lv[lvl].sf + (int64_t)nslab * w.lv[lvl].sf_step;
+                }
+                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st, fapply_done, sf_next);
+                fapply_done = sf_next != nullptr;
             }
             if (rc) return rc;
         }

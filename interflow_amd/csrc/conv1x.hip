@@ -268,6 +268,7 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
     }
     XT_PUT(5, (unsigned long long)xt_bar); XT_PUT(6, (unsigned long long)(XT_CLK() - xt_c1)); XT_PUT(7, (unsigned long long)xt_pass);
     XT_STAMP(2);
+    (void)xt_bar; (void)xt_pass; (void)xt_c1;
 
     // ---- output transform ----------------------------------------------------------------------------------------------------
     // stage 1 along i (partner: other bi = wave ^ 2), in two rounds (jl = 0,1 then jl = 2: 32 + 16 slots of 4 KB)

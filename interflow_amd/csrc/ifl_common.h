@@ -185,7 +185,8 @@ int ifl_k_unsqueeze_ring(const float* b, float* a, int B, int C, int H, int W, h
 int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, int f, int reverse, hipStream_t st);
 int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st);
 // pointwise.hip
-int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st);            // in place on ringed NHWC
+// in place on ringed NHWC; sf_next (decode only, may be NULL): also apply the next layer's z = (z + shiftFt) * scaleFt
+int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, const float* sf_next, hipStream_t st);
 // ld_out = ld_in + constant + sum ldpart[0, slots_used) + fsign * (sum ldpart[fa0, fa0+fan) + sum ldpart[fb0, fb0+fbn))
 int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const float* ld_in, float* ld_out,
                       double constant, double fsign, int fa0, int fan, int fb0, int fbn, int B, hipStream_t st);

@@ -18,7 +18,8 @@ namespace {
 // wave, whose loads all complete (they feed the arithmetic) before its stores issue.
 template <int C, int SPLIT>
 __global__ __launch_bounds__(256)
-void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse)
+void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse,
+                 const float* __restrict__ sfnext)
 {
     constexpr int CO = C / SPLIT;
     static_assert(CO % 4 == 0 && 256 % SPLIT == 0, "outputs per thread must be whole 16-byte words");
@@ -33,7 +34,8 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
     const int part = (int)(t0 - p * SPLIT);
     if (p >= (int64_t)B * H * W) return;
     int x = p % W; int64_t t = p / W; int y = t % H; int b = t / H;
-    float* px = zr + (((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C;
+    const int64_t pxi = ((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1;
+    float* px = zr + pxi * C;
     float v[C], o[CO];
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
@@ -60,6 +62,15 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
 #pragma unroll
         for (int c = 0; c < CO; ++c) { o[c] = o[c] * ss[co0 + c]; o[c] = o[c] - sb[co0 + c]; }
     }
+    if (sfnext) {                    // the next layer's z = (z + shiftFt) * scaleFt (FlowAffineCouplingsAblation.py:170-175), fused
+        const float* sf = sfnext + pxi * (2 * C) + 2 * co0;
+#pragma unroll
+        for (int c = 0; c < CO; c += 2) {
+            const f32x4 f = *(const f32x4*)(sf + 2 * c);
+            o[c] = o[c] + f[0]; o[c] = o[c] * f[1];
+            o[c + 1] = o[c + 1] + f[2]; o[c + 1] = o[c + 1] * f[3];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < CO; c += 4) *(f32x4*)(px + co0 + c) = f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]};
 }
@@ -73,7 +84,8 @@ void anic_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, i
 __device__ __forceinline__ f32x4 mfma16p(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __global__ __launch_bounds__(256)
-void anic48_mfma_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse)
+void anic48_mfma_kernel(float* __restrict__ zr, const float* __restrict__ prm, int B, int H, int W, int inverse,
+                        const float* __restrict__ sfnext)
 {
     constexpr int C = 48;
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
@@ -94,7 +106,8 @@ void anic48_mfma_kernel(float* __restrict__ zr, const float* __restrict__ prm, i
         const bool live = p < total;
         const int64_t pc = live ? p : total - 1;
         const int x = pc % W; const int64_t q = pc / W; const int y = q % H; const int b = q / H;
-        float* px = zr + (((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + 4 * g;
+        const int64_t pxi = ((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1;
+        float* px = zr + pxi * C + 4 * g;
         f32x4 v[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) v[j] = *(const f32x4*)(px + 16 * j);
@@ -114,6 +127,17 @@ void anic48_mfma_kernel(float* __restrict__ zr, const float* __restrict__ prm, i
         if (inverse) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) { acc[t] = acc[t] * sc[t]; acc[t] = acc[t] - bb[t]; }
+        }
+        if (sfnext) {                // the next layer's z = (z + shiftFt) * scaleFt, fused
+            const float* sf = sfnext + pxi * (2 * C) + 8 * g;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f32x4 f0 = *(const f32x4*)(sf + 32 * t), f1 = *(const f32x4*)(sf + 32 * t + 4);
+                acc[t][0] = acc[t][0] + f0[0]; acc[t][0] = acc[t][0] * f0[1];
+                acc[t][1] = acc[t][1] + f0[2]; acc[t][1] = acc[t][1] * f0[3];
+                acc[t][2] = acc[t][2] + f1[0]; acc[t][2] = acc[t][2] * f1[1];
+                acc[t][3] = acc[t][3] + f1[2]; acc[t][3] = acc[t][3] * f1[3];
+            }
         }
         if (live) {
 #pragma unroll
@@ -218,12 +242,12 @@ void lerp_kernel(const float* __restrict__ za, const float* __restrict__ zb, con
 
 }  // namespace
 
-int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, hipStream_t st)
+int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, const float* sf_next, hipStream_t st)
 {
     int64_t n = (int64_t)B * H * W;
     dim3 block(256);
-    if (C == 12) hipLaunchKernelGGL((anic_kernel<12, 1>), dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
-    else if (C == 48) hipLaunchKernelGGL(anic48_mfma_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse);
+    if (C == 12) hipLaunchKernelGGL((anic_kernel<12, 1>), dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse, sf_next);
+    else if (C == 48) hipLaunchKernelGGL(anic48_mfma_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, zr, prm, B, H, W, inverse, sf_next);
     else { ifl_set_error("actnorm+invconv: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();
     return 0;
