@@ -7,7 +7,8 @@ sys.path.insert(0, ".")
 from interflow_amd import hip, synth
 from interflow_amd.flow_model import InterpFlow
 
-SCALES, PATCH, B = [1.0, 4.0], 160, 32
+import os
+SCALES, PATCH, B = [1.0, 4.0], 160, int(os.environ.get("EXP_B", "32"))
 dev = torch.device("cuda", 0)
 sd = synth.synth_interpflow_state(SCALES, seed=0)
 model = InterpFlow(SCALES)
@@ -26,6 +27,8 @@ L.ifl_dbgx_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = L.ifl_dbgx_read(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 t = buf.reshape(nwg, 8, 8).astype(np.int64)
+nwg = min(nwg, 32 * ((B * 400 + 31) // 32))        # level-1 workgroups of ifl_cond_prepare: 32 (network, step) pairs x groups
+t = t[:nwg]
 ns = lambda a: a * 10.0          # 100 MHz ticks -> ns
 net = (np.arange(nwg) & 1)       # combo = (id & 7) + ...: net = combo & 1 = id & 1 when ncombo % 8 == 0
 for nname, sel in (("fAffine", net == 0), ("fFeatures", net == 1)):
