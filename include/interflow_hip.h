@@ -126,7 +126,7 @@ int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, vo
                   void* stream);
 
 /* How ifl_flow_encode / ifl_flow_decode spread their work over streams (no counterpart in the reference).
- *   aux_stream      1: the z-independent bulk convolutions run on a library-owned low-priority stream, forked from and
+ *   aux_stream      1: the z-independent bulk convolutions run on a library-owned stream (high priority; IFL_AUX_PRIO_HIGH=0: low), forked from and
  *                   joined to the caller's stream with events, so the per-step chain overlaps them; 0: everything is
  *                   enqueued on the caller's stream in order.
  *   groups          1..4 contiguous sample groups whose chains run on separate library-owned streams.
