@@ -206,6 +206,84 @@ class FlowStep(nn.Module):
         return out, (ld_out if logdet is not None else None)
 
 
+class Split2d(nn.Module):
+    """Split.py:13-125: the conditional split prior of multi-level flows.  A stand-alone
+    operator on the HIP kernels -- its 3x3 Conv2dZeros runs on the library's generic convolution (train_ops.conv2d_ring:
+    ifl_conv2d, and its gradients), the class log-densities on ifl_gaussian_logp (flow_model.Gaussian.logp); the per-pixel
+    arithmetic between them is torch on the device.  The shipped configuration (L=2, flow_model.py:40-46) never creates
+    one, so the fused FlowUpsamplerNet driver does not schedule it (it raises for configurations that would)."""
+
+    def __init__(self, num_channels, logs_eps=0, cond_channels=0, position=None, consume_ratio=0.5, opt=None):
+        super().__init__()
+        self.num_channels_consume = int(round(num_channels * consume_ratio))
+        self.num_channels_pass = num_channels - self.num_channels_consume
+        self.conv = Conv2dZeros(in_channels=self.num_channels_pass + cond_channels, out_channels=self.num_channels_consume * 2)
+        self.logs_eps = opt_get(opt, ['network_G', 'flow', 'split', 'eps'], logs_eps)
+        self.position = position
+        self.opt = opt
+        C = self.num_channels_consume
+        self.I = nn.Parameter(torch.eye(C), requires_grad=False)
+        self.mean_shift = nn.Parameter(torch.zeros(C))
+        self.cov_shift = nn.Parameter(torch.eye(C) * opt_get(opt, ['network_G', 'flow', 'shift', 'std_init_shift'], 1.0))
+
+    def split2d_prior(self, z, ft):                                                       # Split.py:41-45
+        from . import train_ops as T
+        cin = z.shape[1] + (0 if ft is None else ft.shape[1])
+        assert cin == self.conv.weight.shape[1], (cin, tuple(self.conv.weight.shape))
+        src = z if ft is None else torch.cat([z, hip._dev_f32(ft, "Split2d ft")], dim=1)
+        h = T.from_ring(T.conv2d_ring([T.to_ring(src)], [cin], self.conv.weight, self.conv.bias), self.conv.weight.shape[0])
+        h = h * torch.exp(self.conv.logs * self.conv.logscale_factor)                     # flow.py:80-82
+        return h[:, 0::2], h[:, 1::2]                                                      # thops.py:54-55 ("cross")
+
+    def exp_eps(self, logs):                                                              # Split.py:47-51
+        if opt_get(self.opt, ['network_G', 'flow', 'split', 'tanh'], False):
+            return torch.exp(torch.tanh(logs)) + self.logs_eps
+        return torch.exp(logs) + self.logs_eps
+
+    def _class_ll(self, eps, y_onehot):                                                   # Split.py:74-84, 105-113
+        from .flow_model import Gaussian
+        dom_x, dom_y = y_onehot == 0, y_onehot == 1
+        ll = torch.zeros(eps.shape[0], device=eps.device)
+        if bool(dom_x.any()):
+            ll[dom_x] = Gaussian.logp(None, None, eps[dom_x].contiguous())
+        if bool(dom_y.any()):
+            cov_shifted = self.I + torch.matmul(self.cov_shift, self.cov_shift.T)
+            ll[dom_y] = Gaussian.logp(mean=self.mean_shift, cov=cov_shifted, x=eps[dom_y].contiguous())
+        return ll
+
+    def forward(self, input, logdet=0., reverse=False, eps_std=None, eps=None, ft=None, y_onehot=None):
+        x = hip._dev_f32(input, "Split2d input")
+        if type(y_onehot) != torch.Tensor:
+            y_onehot = torch.Tensor(y_onehot)
+        y_onehot = y_onehot.to(x.device)
+        assert len(y_onehot.shape) == 1, 'labels must be one dimensional'                  # Split.py:60
+        if not reverse:
+            z1, z2 = self.split_ratio(x)
+            mean, logs = self.split2d_prior(z1, ft)
+            eps = (z2 - mean) / (self.exp_eps(logs) + 1e-6)
+            assert eps.shape[0] == y_onehot.shape[0], 'need one class label per datapoint'
+            logdet = logdet + self._class_ll(eps, y_onehot) - logs.sum(dim=[1, 2, 3])
+            return z1, logdet, eps
+        z1 = x
+        mean, logs = self.split2d_prior(z1, ft)
+        if eps is None:                                                                    # Split.py:92-103: sample eps
+            std = 1.0 if eps_std is None else eps_std
+            eps = torch.randn(mean.shape, device=mean.device) * std
+            dom_y = y_onehot == 1
+            if bool(dom_y.any()):
+                noise = torch.randn(mean.shape, device=mean.device)[dom_y] * std
+                eps[dom_y] = eps[dom_y] + self.mean_shift.reshape(1, -1, 1, 1) + torch.matmul(self.cov_shift, noise.T).T
+        else:
+            eps = hip._dev_f32(eps, "Split2d eps")
+        assert eps.shape[0] == y_onehot.shape[0], 'need one class label per datapoint'
+        z2 = mean + self.exp_eps(logs) * eps
+        z = torch.cat((z1, z2), dim=1)
+        return z, logdet - self._class_ll(eps, y_onehot) + logs.sum(dim=[1, 2, 3])
+
+    def split_ratio(self, input):                                                         # Split.py:123-125
+        return input[:, :self.num_channels_pass, ...], input[:, self.num_channels_pass:, ...]
+
+
 def _as_logdet(logdet, B, device):
     """The reference accepts a python float (default 0.) or a [B] tensor for logdet."""
     if isinstance(logdet, torch.Tensor):
@@ -275,7 +353,8 @@ class FlowUpsamplerNet(nn.Module):
                 self._kinds.append(("stepc", self.C))
             correction = 0 if opt_get(opt, ['network_G', 'flow', 'split', 'correct_splits'], False) else 1
             if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) and level < self.L - correction:
-                raise NotImplementedError("Split2d layers (Split.py) are not instantiated by the shipped config (L=2)")
+                raise NotImplementedError("Split2d layers are not scheduled by the fused driver (the shipped config, L=2, creates "
+                                          "none); the operator itself is flow_modules.Split2d")
         # dead module the reference registers and never calls (:107-110); kept for the state-dict contract
         n_aff = (len(opt_get(opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []) + 1) * 64
         n_f = 2 * 3 * 64 // 2 // 2 if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) else 2 * 3 * 64

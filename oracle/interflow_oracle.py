@@ -486,3 +486,39 @@ def resize_right(x, scale):
         nb = t[fov]
         out = (nb * w.reshape(*w.shape, *[1] * (x.ndim - 1))).sum(1).transpose(0, dim)
     return out
+
+
+# ----------------------------------------------------------------------------- Split2d
+def split2d(x, logdet, reverse, sd, pfx, y_onehot, ft=None, eps=None, logs_eps=0.0, tanh=False):
+    """models/modules/Split.py:41-122 (Split2d.forward).  `sd[pfx + ...]`: conv.{weight,bias,logs}, mean_shift, cov_shift.
+    Forward: x [B,C,H,W] -> (z1, logdet, eps); reverse (eps given): z1 -> (z, logdet).  y_onehot: 1-D tensor of 0 / 1 domain
+    labels (0: standard normal, 1: N(mean_shift, I + cov_shift cov_shift^T))."""
+    consume = sd[pfx + "conv.weight"].shape[0] // 2
+    dom_x, dom_y = y_onehot == 0, y_onehot == 1
+
+    def prior(z1):
+        z = z1 if ft is None else torch.cat([z1, ft], dim=1)                                   # Split.py:41-45
+        h = conv2d_zeros(z, sd[pfx + "conv.weight"], sd[pfx + "conv.bias"], sd[pfx + "conv.logs"])
+        return split_feature(h, "cross")
+
+    def exp_eps(logs):                                                                           # Split.py:47-51
+        return (torch.exp(torch.tanh(logs)) if tanh else torch.exp(logs)) + logs_eps
+
+    def ll_of(e):                                                                                # Split.py:77-84, 108-113
+        cov = torch.eye(consume, dtype=e.dtype) + sd[pfx + "cov_shift"] @ sd[pfx + "cov_shift"].T
+        ll = torch.zeros(e.shape[0], dtype=e.dtype)
+        if dom_x.any():
+            ll[dom_x] = gaussian_logp(None, None, e[dom_x])
+        if dom_y.any():
+            ll[dom_y] = gaussian_logp(sd[pfx + "mean_shift"], cov, e[dom_y])
+        return ll
+
+    if not reverse:
+        npass = x.shape[1] - consume
+        z1, z2 = x[:, :npass], x[:, npass:]                                                      # Split.py:123-125
+        mean, logs = prior(z1)
+        e = (z2 - mean) / (exp_eps(logs) + 1e-6)
+        return z1, logdet + ll_of(e) - logs.sum(dim=[1, 2, 3]), e
+    mean, logs = prior(x)
+    z2 = mean + exp_eps(logs) * eps
+    return torch.cat((x, z2), dim=1), logdet - ll_of(eps) + logs.sum(dim=[1, 2, 3])

@@ -138,6 +138,29 @@ def test_non_lu_invconv_step_golden(golden_dir, C):
     rel_close(zr, g[f"c{C}.zr"], what="non-LU dec z"); rel_close(lr, g[f"c{C}.lr"], 1e-3, what="non-LU dec logdet")
 
 
+@pytest.mark.parametrize("tag,C,cond", [("a", 48, 320), ("b", 24, 0)])
+def test_split2d_golden(golden_dir, tag, C, cond):
+    """Split2d operator (Split.py:13-125) against the reference module's outputs: both domains in one batch, with and without
+    conditioning features; reverse with the forward's eps restores the input."""
+    from interflow_amd.flow_modules import Split2d
+    g = dict(np.load(os.path.join(golden_dir, "split_seed0.npz")))
+    m = Split2d(num_channels=C, logs_eps=float(g[tag + ".logs_eps"]), cond_channels=cond)
+    m.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith(tag + ".") and k[2:] in
+                       ("conv.weight", "conv.bias", "conv.logs", "I", "mean_shift", "cov_shift")}, strict=True)
+    m.eval().to(dev())
+    ft = t(g[tag + ".ft"]).to(dev()) if cond else None
+    y = t(g[tag + ".y"])
+    with torch.no_grad():
+        z1, ld, eps = m(t(g[tag + ".x"]).to(dev()), logdet=t(g[tag + ".ld"]).to(dev()), reverse=False, ft=ft, y_onehot=y)
+        assert torch.equal(z1.cpu(), t(g[tag + ".z1"]))
+        rel_close(eps, g[tag + ".eps"], what="split eps"); rel_close(ld, g[tag + ".ld_f"], what="split logdet")
+        zr, ldr = m(t(g[tag + ".z1"]).to(dev()), logdet=t(g[tag + ".ld_f"]).to(dev()), reverse=True, eps=t(g[tag + ".eps"]).to(dev()),
+                    ft=ft, y_onehot=y)
+        rel_close(zr, g[tag + ".zr"], what="split reverse z"); rel_close(ldr, g[tag + ".ld_r"], 1e-3, what="split reverse logdet")
+        with pytest.raises(hip.InterflowHipError):
+            m(t(g[tag + ".x"]), logdet=0., reverse=False, ft=ft, y_onehot=y)            # CPU tensor: no fallback
+
+
 # ----------------------------------------------------------------------------- whole stack
 def test_stack32_golden(golden_dir, sd_np, model):
     g = load(golden_dir, "stack32_seed0.npz", sd_np)

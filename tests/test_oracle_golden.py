@@ -97,6 +97,21 @@ def test_non_lu_invconv_step(golden_dir, C):
     close(zr, g[f"c{C}.zr"]); close(lr, g[f"c{C}.lr"], 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_split2d(golden_dir, tag):
+    """Split2d (Split.py:13-125): the reference module's outputs from
+    tests/golden/make_golden_split.py, with and without conditioning features, both domains in one batch."""
+    g = _load(golden_dir, "split_seed0.npz")
+    sdl = {k[2:]: t(v) for k, v in g.items() if k.startswith(tag + ".") and k[2:] in
+           ("conv.weight", "conv.bias", "conv.logs", "mean_shift", "cov_shift")}
+    ft = t(g[tag + ".ft"]) if tag + ".ft" in g else None
+    y, le = t(g[tag + ".y"]), float(g[tag + ".logs_eps"])
+    z1, ld, eps = O.split2d(t(g[tag + ".x"]), t(g[tag + ".ld"]), False, sdl, "", y, ft=ft, logs_eps=le)
+    close(z1, g[tag + ".z1"]); close(eps, g[tag + ".eps"]); close(ld, g[tag + ".ld_f"], 1e-5, 1e-3)
+    zr, ldr = O.split2d(t(g[tag + ".z1"]), t(g[tag + ".ld_f"]), True, sdl, "", y, ft=ft, eps=t(g[tag + ".eps"]), logs_eps=le)
+    close(zr, g[tag + ".zr"]); close(ldr, g[tag + ".ld_r"], 1e-5, 1e-3)
+
+
 def test_gaussian_and_loss(golden_dir, sd):
     g = _load(golden_dir, "ops_seed0.npz")
     z = t(g["g_z"])
