@@ -9,7 +9,7 @@
 // for every 4x4 output tile and its 6x6 input window d (Lavin & Gray's matrices for the points 0, +-1, +-2, inf).  For each of
 // the 36 positions (i, jc) of the transformed domain the sum over input channels is a GEMM
 //   M[co][tile] = U[co][ci] V[ci][tile]     (fp32 throughout; the result differs from the direct form by fp32 rounding only:
-//                                            tools/exp_wino_error.py, tests/test_gpu_parity.py).
+//                                            tests/test_wino_numerics.py, tests/test_gpu_parity.py).
 //
 // Two kernels:
 //   wino4_input_kernel     V = B^T d B of every tile and channel, once per loaded conditioning map (ifl_load_cond): ringed

@@ -1,10 +1,9 @@
-#!/usr/bin/env python
-"""Experiment (CPU, uses the oracle as the checker): how much fp32 rounding error do the Winograd forms F(2x2,3x3) and
-F(4x4,3x3) of the conditioning convolution add to z of a full 160x160 encode, compared with the direct fp32 form and a
-float64 evaluation of the same network?  Decides which minimal-filtering form the bulk kernel may use inside the 1e-4
-tolerance of tests/test_gpu_parity.py.
+"""Numerics of the Winograd forms of the bulk convolution, on the CPU oracle (the checker, not the product): how much fp32
+rounding error do F(2x2,3x3) and F(4x4,3x3) add to z of a full 160x160 encode, compared with the direct fp32 form and a
+float64 evaluation of the same network?  The bound asserted here is what lets the bulk kernel use F(4x4,3x3) inside the
+1e-4 tolerance of tests/test_gpu_parity.py.
 
-    python tools/exp_wino_error.py
+    python tests/test_wino_numerics.py        (prints the three errors)
 """
 import os
 import sys
@@ -13,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repository root
 sys.path.insert(0, ROOT)
 from interflow_amd import synth  # noqa: E402
 from oracle import interflow_oracle as O  # noqa: E402
@@ -62,9 +61,18 @@ def conv2d_actnorm(x, weight, an_bias, an_logs):
     return y
 
 
-def main():
+def errors():
     torch.set_num_threads(8)
+    saved = O.conv2d_actnorm
     O.conv2d_actnorm = conv2d_actnorm
+    try:
+        return _errors()
+    finally:
+        O.conv2d_actnorm = saved
+        MODE["m"] = 0
+
+
+def _errors():
     sd_np = synth.synth_interpflow_state([2, 4], seed=0)
     B, H = 1, 160
     x = torch.from_numpy(synth.synth_images(1, B, H, H))
@@ -75,12 +83,21 @@ def main():
         MODE["m"] = 0
         z64, ld64 = O.flow_encode(x.double(), {k: v.double() for k, v in feats.items()}, sd64, "flow_upsampler.", torch.zeros(B).double())
         ref = float(z64.abs().max())
+        out = {}
         for m in (0, 2, 4):
             MODE["m"] = m
             z, ld = O.flow_encode(x, feats, sd32, "flow_upsampler.", torch.zeros(B))
-            e = float((z.double() - z64).abs().max()) / ref
-            print(f"F({m}x{m},3x3)" if m else "direct     ", f"z max|err|/max|z| vs float64 = {e:.3e}   logdet rel {float(((ld.double() - ld64) / ld64).abs().max()):.2e}", flush=True)
+            out[m] = (float((z.double() - z64).abs().max()) / ref, float(((ld.double() - ld64) / ld64).abs().max()))
+    return out
+
+
+def test_winograd_forms_stay_far_inside_the_tolerance():
+    e = errors()
+    for m, (ez, el) in e.items():
+        print(f"F({m}x{m},3x3)" if m else "direct     ", f"z max|err|/max|z| vs float64 = {ez:.3e}   logdet rel {el:.2e}")
+    assert e[0][0] < 1e-5 and e[2][0] < 1e-5 and e[4][0] < 2e-5           # tolerance of the parity tests: 1e-4
+    assert all(el < 1e-5 for _, el in e.values())
 
 
 if __name__ == "__main__":
-    main()
+    test_winograd_forms_stay_far_inside_the_tolerance()
