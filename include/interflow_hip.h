@@ -163,6 +163,18 @@ int64_t ifl_logp_scratch_floats(int HW);
 int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov,
                       float* scratch, float* out, int B, int C, int H, int W, void* stream);
 
+/* ifl_gaussian_logp for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and the same results, bit for bit, as
+ * ifl_gaussian_logp; the per-block partial sums live in a static device array inside the library (one copy per GPU,
+ * IFL_LOGP_STATIC_MAX_FLOATS floats = 256 KiB, held until the process ends) instead of a caller-owned scratch.  The call
+ * allocates and frees nothing.  Limit: B * ifl_logp_scratch_floats(H*W) <= IFL_LOGP_STATIC_MAX_FLOATS, otherwise
+ * IFL_ENOTSUP (use ifl_gaussian_logp).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * streams, two host threads) race; calls on one stream, or otherwise ordered, are safe (each call overwrites every slot it
+ * later reads, so nothing carries over from the call before).                                                       */
+#define IFL_LOGP_STATIC_MAX_FLOATS 65536
+int ifl_gaussian_logp_static(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* out,
+                             int B, int C, int H, int W, void* stream);
+
 /* Latent interpolation z = wa[b]*za + wb[b]*zb (flow_model.py:186-200, train.py:88-92).
  * wa/wb are per-sample weights in device memory, n_per_sample = C*H*W.                          */
 int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out,

@@ -722,6 +722,16 @@ extern "C" int ifl_gaussian_logp(const float* z, const float* mean, const float*
     return ifl_k_logp(z, mean, cov_inv, logdet_cov, scratch, out, B, C, H * W, (hipStream_t)stream);
 }
 
+extern "C" int ifl_gaussian_logp_static(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* out,
+                                        int B, int C, int H, int W, void* stream)
+{
+    IFL_CHECK_ARG(z && out, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(C >= 1 && C <= 64, IFL_ENOTSUP, "C=%d outside 1..64", C);
+    IFL_CHECK_ARG(cov_inv == nullptr || mean != nullptr, IFL_EINVAL, "cov_inv without mean");
+    IFL_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, IFL_EINVAL, "bad shape");
+    return ifl_k_logp_static(z, mean, cov_inv, logdet_cov, out, B, C, H * W, (hipStream_t)stream);
+}
+
 extern "C" int ifl_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B,
                         int64_t n_per_sample, void* stream)
 {

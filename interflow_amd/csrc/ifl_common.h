@@ -120,6 +120,7 @@ static inline int64_t ifl_vg_floats(int B, int H, int W) {
     IflXGeom g = ifl_xgeom(B, H, W); return (int64_t)((g.ntiles + 31) / 32) * (IFL_FT / IFL_XCH) * 36 * 32 * IFL_XCH;
 }
 
+#define IFL_MAX_DEVICES 64    // per-device state tables (streams, events, static scratch addresses)
 #define IFL_MAX_COND 16       // conditional steps per level (flow_model.py:42 K=16)
 struct IflStepList { int64_t off[IFL_MAX_COND]; };     // float offsets of the steps' parameter blocks
 
@@ -192,6 +193,8 @@ int ifl_k_ld_finalize(const float* ldpart, int slots_used, int ld_slots, const f
                       double constant, double fsign, int fa0, int fan, int fb0, int fbn, int B, hipStream_t st);
 int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* scratch,
                float* out, int B, int C, int HW, hipStream_t st);
+int ifl_k_logp_static(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* out, int B, int C,
+                      int HW, hipStream_t st);                  // scratch = the library's static device array
 int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B,
                int64_t n, hipStream_t st);
 // conv1.hip

@@ -10,6 +10,13 @@
 //   lerp:  z = wa*za + wb*zb                               flow_model.py:186-200, train.py:88-92
 #include "ifl_common.h"
 
+#include <mutex>
+
+// Scratch of ifl_gaussian_logp_static (the entry point that allocates nothing): the per-block partial sums that
+// ifl_gaussian_logp takes from its `scratch` argument.  One copy per GPU, held until the process ends.  In host code this
+// name is only a handle for hipGetSymbolAddress; kernels get the device address that call returns (g_logp_scratch_ptr).
+static __device__ __align__(256) float scratch[IFL_LOGP_STATIC_MAX_FLOATS];
+
 namespace {
 
 // SPLIT threads per pixel of the ringed channels-last plane (adjacent lanes), each producing C / SPLIT of the outputs from all
@@ -277,6 +284,37 @@ int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float lo
 }
 
 int64_t ifl_logp_scratch_floats(int HW) { return ifl_cdiv(HW, LOGP_PIX); }
+
+// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.
+namespace {
+std::mutex g_logp_scratch_mu;
+float* g_logp_scratch_ptr[IFL_MAX_DEVICES] = {};
+}  // namespace
+
+int ifl_k_logp_static(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* out, int B, int C,
+                      int HW, hipStream_t st)
+{
+    const int64_t need = (int64_t)B * ifl_logp_scratch_floats(HW);
+    IFL_CHECK_ARG(need <= IFL_LOGP_STATIC_MAX_FLOATS, IFL_ENOTSUP,
+                  "ifl_gaussian_logp_static: B * ceil(H*W/%d) = %lld partial sums exceed the static scratch of %d floats; "
+                  "use ifl_gaussian_logp with a caller-owned scratch", LOGP_PIX, (long long)need, IFL_LOGP_STATIC_MAX_FLOATS);
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    IFL_CHECK_ARG(dev >= 0 && dev < IFL_MAX_DEVICES, IFL_ENOTSUP, "device index %d", dev);
+    float* ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_logp_scratch_mu);
+        if (!g_logp_scratch_ptr[dev]) {
+            void* p = nullptr;
+            IFL_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            IFL_CHECK_ARG(p != nullptr, IFL_ENOTSUP, "hipGetSymbolAddress returned a null address for the static scratch");
+            g_logp_scratch_ptr[dev] = (float*)p;
+        }
+        ptr = g_logp_scratch_ptr[dev];
+    }
+    // every slot the finalize kernel reads is written by this call's logp kernel first: nothing has to start at zero
+    return ifl_k_logp(z, mean, cov_inv, logdet_cov, ptr, out, B, C, HW, st);
+}
 
 int ifl_k_lerp(const float* za, const float* zb, const float* wa, const float* wb, float* out, int B, int64_t n,
                hipStream_t st)

@@ -80,6 +80,9 @@ def lib():
     L.ifl_logp_scratch_floats.argtypes = [c_int]
     L.ifl_gaussian_logp.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_gaussian_logp_static.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_gaussian_logp_static.restype = c_int
     L.ifl_lerp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
     L.ifl_rrdb_conv_count.argtypes = [c_int]
     L.ifl_rrdb_conv_count.restype = c_int
@@ -122,7 +125,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
-           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad")
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
@@ -269,6 +272,24 @@ def gaussian_logp(z: torch.Tensor, mean=None, cov_inv=None, logdet_cov: float = 
         check(L.ifl_gaussian_logp(_ptr(z), _ptr(mean) if cov_inv is not None else c_void_p(0), _ptr(cov_inv),
                                   float(logdet_cov), _ptr(scratch), _ptr(out), B, C, H, W, _stream()),
               "ifl_gaussian_logp")
+    return out
+
+
+LOGP_STATIC_MAX_FLOATS = 65536
+
+
+def gaussian_logp_static(z: torch.Tensor, out: torch.Tensor, mean=None, cov_inv=None, logdet_cov: float = 0.0) -> torch.Tensor:
+    """ifl_gaussian_logp_static: gaussian_logp into a caller-owned `out` [B], partial sums in the library's static device
+    array -- neither this wrapper nor the library allocates.  Inputs must already be contiguous float32 device tensors."""
+    B, C, H, W = z.shape
+    for t, name in ((z, "z"), (out, "out"), (mean, "mean"), (cov_inv, "cov_inv")):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise InterflowHipError(f"gaussian_logp_static {name}: needs a contiguous float32 GPU tensor")
+    assert out.numel() == B
+    with torch.cuda.device(z.device):
+        check(lib().ifl_gaussian_logp_static(_ptr(z), _ptr(mean) if cov_inv is not None else c_void_p(0), _ptr(cov_inv),
+                                             float(logdet_cov), _ptr(out), B, C, H, W, _stream()),
+              "ifl_gaussian_logp_static")
     return out
 
 
