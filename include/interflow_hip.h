@@ -16,6 +16,11 @@
  *   - every function returns 0 on success, a negative IFL_E* code on a rejected argument, or a
  *     positive hipError_t; ifl_last_error() gives the text for the calling thread.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - threads: entry points may be called from several host threads.  The flow drivers (ifl_flow_encode/decode/pass) share
+ *     one set of library-owned streams and events per device; a per-device mutex serialises their ENQUEUE sequences, so calls
+ *     from different threads or on different caller streams are each correct (their bulk phases queue one behind the other on
+ *     the shared auxiliary stream).  Two calls must not use the same workspace at the same time.  ifl_set_schedule,
+ *     ifl_set_conv1_algo and ifl_prof_enable change process-wide settings: call them while no other thread is inside a driver.
  */
 #ifndef INTERFLOW_HIP_H
 #define INTERFLOW_HIP_H

@@ -20,19 +20,23 @@ void ifl_set_error(const char* fmt, ...)
 extern "C" const char* ifl_last_error(void) { return g_err; }
 
 // ---- opt-in per-kernel timing with HIP events on the caller's stream (used by bench.py for the roofline figure) ----
+#include <atomic>
+#include <mutex>
 #include <vector>
 namespace {
 struct ProfRec { int id; hipEvent_t a, b; };
-unsigned g_prof_mask = 0;      // bit i set: time kernel id i
+std::atomic<unsigned> g_prof_mask{0};      // bit i set: time kernel id i
+std::mutex g_prof_mu;                      // guards g_prof (drivers may be called from several host threads)
 std::vector<ProfRec> g_prof;
 struct ProfScope {
     hipStream_t st; hipEvent_t b = nullptr;
     ProfScope(int id, hipStream_t s) : st(s) {
-        if (!((g_prof_mask >> id) & 1u)) return;
+        if (!((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1u)) return;
         ProfRec r{id, nullptr, nullptr};
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         (void)hipEventRecord(r.a, st);
         b = r.b;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(r);
     }
     ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
@@ -41,6 +45,7 @@ struct ProfScope {
 
 extern "C" int ifl_prof_enable(int mask)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!mask) {
         for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         g_prof.clear();
@@ -52,6 +57,7 @@ extern "C" int ifl_prof_enable(int mask)
 extern "C" int ifl_prof_read(int kernel_id, double* total_ms, int64_t* count)
 {
     double tot = 0; int64_t n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         if (r.id != kernel_id) continue;
         float ms = 0;
@@ -299,18 +305,23 @@ namespace {
 int env_int(const char* name, int dflt);
 constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
 struct ForkCtx {
+    std::mutex mu;       // held while a driver call enqueues its work: the events below are re-recorded by every call, and a
+                         // wait captures an event's state when it is enqueued, so calls from several host threads / caller
+                         // streams on one device are correct as long as their enqueue sequences do not interleave
     bool ok = false;
     hipStream_t aux, s[IFL_MAX_GROUPS - 1];
     hipEvent_t fork, aux_done, join[IFL_MAX_GROUPS - 1], p1[MAX_P1_EVENTS];
 };
-ForkCtx g_fork[64];
+ForkCtx g_fork[IFL_MAX_DEVICES];
 
-int fork_ctx(ForkCtx** out)
+// the context of the current device; the caller holds f->mu from here to the end of its enqueue sequence
+int fork_ctx(ForkCtx** out, std::unique_lock<std::mutex>* lock)
 {
     int dev = 0;
     IFL_HIP(hipGetDevice(&dev));
-    IFL_CHECK_ARG(dev >= 0 && dev < 64, IFL_ENOTSUP, "device index %d", dev);
+    IFL_CHECK_ARG(dev >= 0 && dev < IFL_MAX_DEVICES, IFL_ENOTSUP, "device index %d", dev);
     ForkCtx& f = g_fork[dev];
+    *lock = std::unique_lock<std::mutex>(f.mu);
     if (!f.ok) {
         int lo = 0, hi = 0;
         IFL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent
@@ -340,8 +351,10 @@ int env_int(const char* name, int dflt)
 struct Sched { int aux, groups, chunk, chunk2; };      // chunk: level-1 steps per bulk launch, chunk2: deeper levels
 Sched& sched()
 {
-    static Sched s{env_int("IFL_AUX_STREAM", 1), env_int("IFL_GROUPS", 2), env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK),
-                   env_int("IFL_P1_CHUNK_STEPS_L2", IFL_P1_CHUNK_L2)};
+    auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };      // as ifl_set_schedule validates
+    static Sched s{env_int("IFL_AUX_STREAM", 1) != 0, clamp(env_int("IFL_GROUPS", 2), 1, IFL_MAX_GROUPS),
+                   clamp(env_int("IFL_P1_CHUNK_STEPS", IFL_P1_CHUNK), 1, IFL_MAX_COND),
+                   clamp(env_int("IFL_P1_CHUNK_STEPS_L2", IFL_P1_CHUNK_L2), 1, IFL_MAX_COND)};
     return s;
 }
 
@@ -514,9 +527,10 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
     const int64_t n_img = (int64_t)3 * H * W, n_lat = (int64_t)48 * (H / 4) * (W / 4);
     const int64_t n_src = decode ? n_lat : n_img, n_dst = decode ? n_img : n_lat;
     ForkCtx* f = nullptr;
+    std::unique_lock<std::mutex> fork_lock;
     hipEvent_t* ev = nullptr;
     if (use_aux || G > 1) {
-        if ((rc = fork_ctx(&f))) return rc;
+        if ((rc = fork_ctx(&f, &fork_lock))) return rc;
         IFL_HIP(hipEventRecord(f->fork, st));
     }
     if (use_aux) {

@@ -389,13 +389,16 @@ class InterpFlow(nn.Module):
         means, covs = self._shifted(z.device)
         # log-density of every sample under every class prior: one HIP pass per class (flow_model.py:156-160)
         ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
+        classes = torch.tensor(np.tile(self.classes, reps=z.shape[0]).reshape((z.shape[0], -1)), device=z.device)
+        mask_label = (classes == label.reshape(-1, 1))
+        # flow_model.py:143-160 ASSIGNS: ll[label == c] = class-c log-density, and the 'X' (label 0) rows are written again by
+        # the second loop, so a label-0 sample ends with the standard-normal log-density even when 0 is one of the classes
         ll = torch.zeros(z.shape[0], device=z.device)
+        for i in range(len(self.classes)):
+            ll = torch.where(mask_label[:, i], ll_all[:, i], ll)
         is_x = label == 0
         if bool(is_x.any()):
             ll = torch.where(is_x, Gaussian.logp(None, None, z), ll)
-        classes = torch.tensor(np.tile(self.classes, reps=z.shape[0]).reshape((z.shape[0], -1)), device=z.device)
-        mask_label = (classes == label.reshape(-1, 1))
-        ll = ll + (ll_all * mask_label).sum(dim=1)
         ll_ib = ll_all / float(pixels)
         ll_ib = torch.log_softmax(ll_ib, dim=1)
         ll_ib = torch.masked_select(ll_ib, mask_label)

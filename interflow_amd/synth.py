@@ -71,7 +71,7 @@ def _invconv_params(rng, C):
     }
 
 
-def _coupling_net(rng, prefix, cin, cout, in_ms, sd, zeros_std):
+def _coupling_net(rng, prefix, cin, cout, in_ms, sd, zeros_std, zeros_bias_std=None):
     """One `F(...)` stack of reference FlowAffineCouplingsAblation.py:248-256.
     in_ms: assumed mean-square of each input channel (array of len cin), used to pick the
     ActNorm log-scale analytically."""
@@ -86,13 +86,16 @@ def _coupling_net(rng, prefix, cin, cout, in_ms, sd, zeros_std):
     sd[prefix + "2.actnorm.bias"] = _f32((rng.uniform(-0.3, 0.3, HIDDEN) * np.sqrt(var2)).reshape(1, HIDDEN, 1, 1))
     sd[prefix + "2.actnorm.logs"] = _f32((-0.5 * np.log(var2) + rng.uniform(-0.1, 0.1, HIDDEN)).reshape(1, HIDDEN, 1, 1))
     sd[prefix + "4.weight"] = _f32(rng.standard_normal((cout, HIDDEN, 3, 3)) * zeros_std)
-    sd[prefix + "4.bias"] = _f32(rng.standard_normal(cout) * zeros_std * 4)
+    sd[prefix + "4.bias"] = _f32(rng.standard_normal(cout) * (zeros_std * 4 if zeros_bias_std is None else zeros_bias_std))
     sd[prefix + "4.logs"] = _f32(rng.uniform(-0.1, 0.1, (cout, 1, 1)))
 
 
 def synth_flow_state(seed: int = 0, L: int = N_LEVELS, K: int = K_STEPS, extra: int = N_EXTRA,
-                     ft_rms: float = 1.0, zeros_std: float = 0.02, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
-    """State dict of a `FlowUpsamplerNet` (keys `layers.{i}.*`, `f.0.*`), as numpy float32."""
+                     ft_rms: float = 1.0, zeros_std: float = 0.02, prefix: str = "",
+                     zeros_bias_std=None) -> "OrderedDict[str, np.ndarray]":
+    """State dict of a `FlowUpsamplerNet` (keys `layers.{i}.*`, `f.0.*`), as numpy float32.  zeros_std: std of the
+    `Conv2dZeros` weights (how much the coupling scales vary from pixel to pixel); zeros_bias_std: std of their biases
+    (how much they vary from channel to channel; default 4 * zeros_std)."""
     rng = np.random.default_rng([seed, 0xF10])
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     first = True
@@ -118,8 +121,8 @@ def synth_flow_state(seed: int = 0, L: int = N_LEVELS, K: int = K_STEPS, extra: 
         if kind == "stepc":
             ms_ft = np.full(N_RRDB_CH, ft_rms ** 2)
             _coupling_net(rng, p + "affine.fAffine.", C // 2 + N_RRDB_CH, (C - C // 2) * 2,
-                          np.concatenate([np.ones(C // 2), ms_ft]), sd, zeros_std)
-            _coupling_net(rng, p + "affine.fFeatures.", N_RRDB_CH, C * 2, ms_ft, sd, zeros_std)
+                          np.concatenate([np.ones(C // 2), ms_ft]), sd, zeros_std, zeros_bias_std)
+            _coupling_net(rng, p + "affine.fFeatures.", N_RRDB_CH, C * 2, ms_ft, sd, zeros_std, zeros_bias_std)
     # dead module registered by the reference (FlowUpsamplerNet.py:107-108), never called
     sd[f"{prefix}f.0.weight"] = _f32(rng.standard_normal((2 * 3 * 64 // 2 // 2, N_RRDB_CH, 3, 3)) * 0.01)
     sd[f"{prefix}f.0.bias"] = _f32(np.zeros(2 * 3 * 64 // 2 // 2))
@@ -162,11 +165,11 @@ def synth_rrdb_state(seed: int = 0, nf: int = 64, nb: int = 23, gc: int = 32, in
 
 
 def synth_interpflow_state(scales, seed: int = 0, mean_init: float = 0.001, std_init: float = 1.0,
-                           ft_rms: float = 1.0, zeros_std: float = 0.02, shift_noise: float = 0.05):
+                           ft_rms: float = 1.0, zeros_std: float = 0.02, shift_noise: float = 0.05, zeros_bias_std=None):
     """Full `InterpFlow` state dict with the reference's aliased key set
     (reference flow_model.py:53-80, RRDBGlowNet_arch.py:49-59)."""
     rng = np.random.default_rng([seed, 0x1F])
-    flow = synth_flow_state(seed, ft_rms=ft_rms, zeros_std=zeros_std)
+    flow = synth_flow_state(seed, ft_rms=ft_rms, zeros_std=zeros_std, zeros_bias_std=zeros_bias_std)
     rrdb = synth_rrdb_state(seed)
     C = 48
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()

@@ -14,6 +14,7 @@ import ctypes
 
 import torch
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import hip
 
@@ -98,11 +99,15 @@ class _ConvRing(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         weight, *srcs = ctx.saved_tensors
         splits, cout, cout_pad, taps, B, h, w, has_bias = ctx.meta
         L = hip.lib()
-        g = torch.zeros_like(gout)                        # zero ring and zero padded channels, whatever arrives
+        # a fresh contiguous [B, h+2, w+2, cout_pad] buffer (the kernels index it as such, whatever strides gout has):
+        # zero ring and zero padded channels, whatever arrives
+        g = torch.zeros(gout.shape, dtype=torch.float32, device=gout.device)
+        assert g.is_contiguous()
         g[:, 1:-1, 1:-1, :cout] = gout[:, 1:-1, 1:-1, :cout]
         cin_pad = sum(p for _, p in splits)
         grads = [None, None, None]

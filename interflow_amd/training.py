@@ -115,6 +115,50 @@ def broadcast_parameters(model: torch.nn.Module, dist, src: int = 0):
         dist.broadcast(t.data, src)
 
 
+def _uninitialised_actnorms(model):
+    """ActNorms in training mode whose data-dependent initialisation is still due (FlowActNorms.py:29-35: `inited` unset
+    and the bias all zero; a module with a non-zero bias is marked initialised, as the reference does).  One device
+    synchronisation for all candidates, none once every module is marked."""
+    from .flow_modules import ActNorm2d
+    cands = [m for m in model.modules() if isinstance(m, ActNorm2d) and m.training and not m.inited]
+    if not cands:
+        return []
+    nonzero = torch.stack([(m.bias != 0).any() for m in cands]).cpu().tolist()
+    todo = []
+    for m, nz in zip(cands, nonzero):
+        if nz:
+            m.inited = True
+        else:
+            todo.append(m)
+    return todo
+
+
+def init_actnorm(model, gt, low_res, dist=None, lr_enc=None, src: int = 0):
+    """Data-dependent ActNorm initialisation (FlowActNorms.py:29-43, and inside every flow.Conv2d, flow.py:57-63) as a step
+    of its own, BEFORE the first optimizer step: one gradient-enabled forward whose result is dropped (each rank initialises
+    from its own batch, as the reference's first training forward does), then every replica takes rank `src`'s parameters,
+    so that data-parallel replicas start identical (only gradients are averaged afterwards).  Returns the number of ActNorms
+    that were initialised; 0 (and no forward, no collective) when there was nothing to do on any rank."""
+    todo = _uninitialised_actnorms(model)
+    n = len(todo)
+    multi = dist is not None and dist.get_world_size() > 1
+    if multi:                                   # every rank must take the same branch: the broadcast below is a collective
+        flag = torch.tensor([float(n)], device=gt.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        n = int(flag.item())
+    if n == 0:
+        return 0
+    with torch.enable_grad():
+        if lr_enc is None:
+            lr_enc = model.arch.rrdbPreprocessing(gt)
+        model(low_res, gt, lr_enc=lr_enc, add_gt_noise=False, calc_loss=False)
+    for m in todo:
+        m.inited = True
+    if multi:
+        broadcast_parameters(model, dist, src)
+    return n
+
+
 def make_optimizer(model: torch.nn.Module, lr: float = 1e-4):
     """train.py:53-56: Adam over the parameters that require grad, MultiStepLR(50000, 75000, 90000; 0.5)."""
     seen, params = set(), []
@@ -156,7 +200,15 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
                interpolate_weight=None):
     """One iteration of train.py:66-131.  interp = (img_lr1, scale1, img_lr2, scale2) enables the LR-consistency term
     (weight consistency_lambda; train.py's default is 10).  Returns a dict of python floats (this synchronises, as the
-    reference's progress bar does at train.py:133-134) and `skipped`."""
+    reference's progress bar does at train.py:133-134) and `skipped`.
+
+    Data parallel (reducer given): uninitialised ActNorms are initialised and broadcast first (`init_actnorm`), and the
+    reference's skip guards (train.py:113-126) are decided collectively -- if ANY rank's loss is non-finite or too large,
+    every rank drops the update and no gradient is exchanged, so a NaN on one rank can neither reach the other replicas'
+    parameters nor make the replicas diverge."""
+    dist = reducer.dist if reducer is not None else None
+    if model.training:
+        init_actnorm(model, gt, low_res, dist)
     lr_enc = model.arch.rrdbPreprocessing(gt)                                           # train.py:72
     z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc, add_gt_noise=add_gt_noise)     # :73
     ib_loss = -torch.mean(ll_ib)                                                        # :74
@@ -169,14 +221,19 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
     loss = nll_loss + consistency_lambda * cons + ib_lambda * ib_loss                   # :110
     out = {"skipped": False}
     bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss.detach()) > 30)         # :113-126
+    if dist is not None and dist.get_world_size() > 1:
+        flag = torch.tensor([1.0 if bad else 0.0], device=gt.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = bool(flag.item() > 0)
     if bad:
+        # The reference calls loss.backward() and continues: those gradients are cleared by the next update's
+        # optimizer.zero_grad() before anything reads them, so the backward only frees the graph.  Here the graph is
+        # simply dropped, and -- the decision being collective -- no rank feeds an all-reduce this iteration.
         out["skipped"] = True
         if reducer is not None:
             reducer.zero_grad()
-        loss.backward()                                     # the reference backpropagates and drops the update
-        if reducer is not None:
-            reducer.finish()
-            reducer.zero_grad()
+        else:
+            optimizer.zero_grad()
     else:
         if reducer is not None:
             reducer.zero_grad()

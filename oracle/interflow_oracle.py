@@ -77,6 +77,10 @@ def actnorm(x, bias, logs, logdet=None, reverse=False):
     """models/modules/FlowActNorms.py:45-97 (eval mode, already initialised).
     fwd: (x + b) * exp(logs); rev: x * exp(-logs) - b; dlogdet = sum(logs) * H*W."""
     assert x.dim() == 4 and x.size(1) == bias.size(1)      # FlowActNorms.py:104-109
+    if _TRAIN_INIT[0] and not bool((bias != 0).any()):     # FlowActNorms.py:29-35,47-48: training mode, first call
+        b, l = actnorm_init(x)
+        bias.copy_(b)                                      # the reference writes its parameters in place (:41-42)
+        logs.copy_(l)
     if not reverse:
         x = x + bias
         x = x * torch.exp(logs)
@@ -90,6 +94,21 @@ def actnorm(x, bias, logs, logdet=None, reverse=False):
     if reverse:
         x = x - bias
     return x, logdet
+
+
+_TRAIN_INIT = [False]
+
+
+class training_init:
+    """`with training_init():` -- evaluate like the reference in train() mode on uninitialised ActNorms: every ActNorm
+    (FlowActNorms.py:29-43; also the one inside each flow.Conv2d, flow.py:57-63) whose bias is still all zero takes its
+    bias / logs from the statistics of the tensor it sees, writing them into the state dict's tensors in place."""
+
+    def __enter__(self):
+        self.prev, _TRAIN_INIT[0] = _TRAIN_INIT[0], True
+
+    def __exit__(self, *a):
+        _TRAIN_INIT[0] = self.prev
 
 
 def actnorm_init(x, scale=1.0):
@@ -115,8 +134,8 @@ def invconv_weight(p, l, u, log_s, sign_s, reverse):
     if not reverse:
         w = torch.matmul(p, torch.matmul(lm, um))
     else:
-        li = torch.inverse(lm.double()).float()
-        ui = torch.inverse(um.double()).float()
+        li = torch.inverse(lm.double()).to(p.dtype)         # .float() in the reference; p.dtype so that a float64 evaluation
+        ui = torch.inverse(um.double()).to(p.dtype)         # of the whole network (tests: numerical noise floor) stays float64
         w = torch.matmul(ui, torch.matmul(li, p.inverse()))
     return w
 
@@ -134,7 +153,7 @@ def invconv(x, p, l, u, log_s, sign_s, logdet=None, reverse=False):
 def invconv_plain(x, weight, logdet=None, reverse=False):
     """models/modules/Permutations.py:78-86 (non-LU branch: a `weight` key in the state dict)."""
     d = torch.slogdet(weight)[1] * pixels(x)
-    w = weight if not reverse else torch.inverse(weight.double()).float()
+    w = weight if not reverse else torch.inverse(weight.double()).to(weight.dtype)
     z = F.conv2d(x, w.view(w.shape[0], w.shape[1], 1, 1))
     if logdet is not None:
         logdet = logdet + d if not reverse else logdet - d

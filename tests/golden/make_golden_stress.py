@@ -1,0 +1,135 @@
+"""Stress goldens from the REFERENCE itself (authoring container only; see make_golden.py for how it is imported).
+
+The seed-0 fixtures are benign: `zeros_std=0.02` keeps every coupling scale in ~0.85-0.91.  These use a second weight seed,
+`zeros_std` large enough that the scales `sigmoid(h+2)+0.001` span ~0.02-0.999, and conditioning features of rms 2, so the
+error amplification through the 32 divisions by the scale ("hard parts") is exercised.  With couplings
+that wide, analytically chosen ActNorm parameters no longer keep |z| bounded (the stack overflows to NaN, as SURVEY 8(c)
+notes for naive random states), so the ActNorm parameters are the ones the REFERENCE's own data-dependent initialisation
+(FlowActNorms.py:29-43: one train-mode forward on a seeded 160x160 batch) produces for these weights; they are stored in the
+fixture (`an_*`, 328 small tensors) and `tests/_stress.py` puts them back into the synthesised state on the GPU box.
+
+  stress32   32x32,  B=2: full z / x_rec / logdets
+  stress160  160x160, B=2: full z / x_rec / logdets
+  stress512  512x512, B=1: float64 checksums (sum, sum of squares) + every 16th element of z and x_rec  (BASELINE configs[4] size)
+  aninit     the reference's data-dependent ActNorm initialisation (FlowActNorms.py:29-43, flow.py:57-63): weights with every
+             ActNorm zeroed, train mode, one forward on a 32x32 batch of 4 -> bias / logs of all 164 ActNorms, z, logdet
+
+usage: python tests/golden/make_golden_stress.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import import_reference, t  # noqa: E402
+from interflow_amd import synth  # noqa: E402
+
+SEED, ZEROS_STD, FT_RMS = 1, float(os.environ.get('IFL_STRESS_ZSTD', '0.03')), 2.0
+BIAS_STD = float(os.environ.get('IFL_STRESS_BSTD', '1.0'))
+STRIDE = 16
+
+
+def main():
+    torch.manual_seed(0)
+    np.random.seed(0)
+    torch.set_num_threads(8)
+    InterpFlow, rflow = import_reference()
+    scales = [2, 4]
+    sd_np = synth.synth_interpflow_state(scales, seed=SEED, ft_rms=FT_RMS, zeros_std=ZEROS_STD, zeros_bias_std=BIAS_STD)
+    for k in sd_np:
+        if k.endswith("actnorm.bias") or k.endswith("actnorm.logs"):
+            sd_np[k] = np.zeros_like(sd_np[k])
+    model = InterpFlow(scales=scales)
+    model.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+    model.train()
+    fu = model.flow_upsampler
+    with torch.no_grad():                     # the reference's data-dependent ActNorm initialisation
+        xi = synth.synth_images(29, 2, 160, 160)
+        fi = {k: t(v) for k, v in synth.synth_features(30, 2, 160, 160, rms=FT_RMS).items()}
+        fu(gt=t(xi), rrdbResults=fi, logdet=torch.zeros(2), reverse=False, y_onehot=torch.zeros(2), test_input_size=160)
+    model.eval()
+    an = {k: v.numpy().copy() for k, v in fu.state_dict().items() if k.endswith("actnorm.bias") or k.endswith("actnorm.logs")}
+    assert len(an) == 328
+    for k, v in an.items():
+        for pre in ("flow_upsampler.", "arch.flowUpsamplerNet."):
+            sd_np[pre + k] = v
+    out = {"an_" + k: v for k, v in an.items()}
+    out.update({"digest": np.array(synth.state_digest(sd_np)), "seed": np.array(SEED), "zeros_std": np.array(ZEROS_STD),
+           "ft_rms": np.array(FT_RMS), "zeros_bias_std": np.array(BIAS_STD), "stride": np.array(STRIDE)})
+    with torch.no_grad():
+        # how wide the coupling scales are (documentation of the regime, one step of each level)
+        for li in (3, 22):
+            step = fu.layers[li]
+            C = step.actnorm.bias.shape[1]
+            ft = t(synth.synth_features(40 + li, 1, 64, 64, rms=FT_RMS)["fea_up4"][:, :, :16, :16])
+            h = step.affine.fFeatures(ft)
+            sc = torch.sigmoid(h[:, 1::2] + 2.) + 0.001
+            print(f"layer {li} C={C}: scaleFt min {sc.min():.4f} p1 {sc.quantile(0.01):.4f} median {sc.median():.4f} max {sc.max():.4f}")
+            out[f"scale_range_{li}"] = np.array([sc.min().item(), sc.quantile(0.01).item(), sc.median().item(), sc.max().item()])
+        for tag, B, H, xs, fs in (("s32", 2, 32, 31, 32), ("s160", 2, 160, 33, 34), ("s512", 1, 512, 35, 36)):
+            x = synth.synth_images(xs, B, H, H)
+            feats = {k: t(v) for k, v in synth.synth_features(fs, B, H, H, rms=FT_RMS).items()}
+            z, ld = fu(gt=t(x), rrdbResults=feats, logdet=torch.zeros(B), reverse=False, y_onehot=torch.zeros(B),
+                       test_input_size=H)
+            xr, ldr = fu(z=z, rrdbResults=feats, logdet=torch.zeros(B), reverse=True, y_onehot=torch.zeros(B),
+                         test_input_size=H)
+            print(f"{tag}: z std {z.std():.3f} |z|max {z.abs().max():.2f}  |x-xr|max {(xr - t(x)).abs().max():.3e}  ld {ld.numpy()} ldr {ldr.numpy()}")
+            if os.environ.get("IFL_STRESS_SCAN"):
+                break
+            assert torch.isfinite(z).all() and torch.isfinite(xr).all()
+            out[f"{tag}_ld"], out[f"{tag}_ldr"] = ld.numpy(), ldr.numpy()
+            if H < 512:
+                out[f"{tag}_z"], out[f"{tag}_xr"] = z.numpy(), xr.numpy()
+                # float64 evaluation of the same network (the oracle's formulas -- bit-identical to the reference in
+                # float32, tests/test_oracle_golden.py -- with float64 tensors): what the outputs would be without
+                # rounding.  z64 = encode64(x); xr64 = decode64(the reference's float32 z).  Stored rounded to float32.
+                from oracle import interflow_oracle as O
+                sd64 = {k: v.double() for k, v in O.to_torch(sd_np).items()}
+                f64 = {k: v.double() for k, v in feats.items()}
+                z64, _ = O.flow_encode(t(x).double(), f64, sd64, "flow_upsampler.", torch.zeros(B).double(), test_input_size=H)
+                xr64, _ = O.flow_decode(z.double(), f64, sd64, "flow_upsampler.", torch.zeros(B).double(), test_input_size=H)
+                out[f"{tag}_z64"], out[f"{tag}_xr64"] = z64.float().numpy(), xr64.float().numpy()
+                rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+                print(f"   reference fp32 vs float64: z {rel(z, z64):.2e}  x_rec {rel(xr, xr64):.2e}   (x_rec64 vs x {rel(xr64, t(x).double()):.2e})")
+            else:
+                for name, v in (("z", z), ("xr", xr)):
+                    out[f"{tag}_{name}_sample"] = v.reshape(-1)[::STRIDE].numpy().copy()
+                    out[f"{tag}_{name}_sum"] = v.double().sum().numpy()
+                    out[f"{tag}_{name}_sumsq"] = v.double().square().sum().numpy()
+                    out[f"{tag}_{name}_absmax"] = v.abs().max().numpy()
+    if os.environ.get("IFL_STRESS_SCAN"):
+        return
+    np.savez_compressed(os.path.join(HERE, "stress_seed1.npz"), **out)
+
+    # ---- data-dependent ActNorm initialisation --------------------------------------------------------------------
+    sd0 = synth.synth_interpflow_state(scales, seed=0)
+    for k in sd0:
+        if k.endswith("actnorm.bias") or k.endswith("actnorm.logs"):
+            sd0[k] = np.zeros_like(sd0[k])
+    model = InterpFlow(scales=scales)
+    model.load_state_dict({k: t(v) for k, v in sd0.items()}, strict=True)
+    model.train()
+    B, H = 4, 32
+    x = synth.synth_images(51, B, H, H)
+    feats = {k: t(v) for k, v in synth.synth_features(52, B, H, H).items()}
+    with torch.no_grad():
+        z, ld = model.flow_upsampler(gt=t(x), rrdbResults=feats, logdet=torch.zeros(B), reverse=False, y_onehot=torch.zeros(B),
+                                     test_input_size=H)
+    an = {"z": z.numpy(), "ld": ld.numpy()}
+    n = 0
+    for k, v in model.flow_upsampler.state_dict().items():
+        if k.endswith("actnorm.bias") or k.endswith("actnorm.logs"):
+            an["p_" + k] = v.numpy().copy()
+            n += 1
+    print("aninit: %d ActNorm tensors, z std %.3f, ld %s" % (n, z.std().item(), ld.numpy()))
+    assert n == 2 * 164 and all(np.any(v != 0) for k, v in an.items() if k.endswith("bias"))
+    np.savez_compressed(os.path.join(HERE, "aninit_seed0.npz"), **an)
+    for fn in ("stress_seed1.npz", "aninit_seed0.npz"):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)))
+
+
+if __name__ == "__main__":
+    main()

@@ -11,13 +11,13 @@ from tests.test_shard import _free_port
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, out):
+def _run(world, out, worker="_ddp_worker.py", *extra):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_ddp_worker.py"), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, worker), out, *extra], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=240)
@@ -32,3 +32,17 @@ def test_gradient_allreduce_and_broadcast_two_ranks(tmp_path):
     for k in a.files:
         np.testing.assert_allclose(b[k], a[k], rtol=2e-5, atol=1e-7, err_msg=k)
     assert np.all(a["g_dead.weight"] == 0) and np.all(b["g_dead.weight"] == 0)      # never-used parameters stay zero
+
+
+import pytest
+
+
+@pytest.mark.parametrize("mode", ["plain", "nan", "large"])
+def test_train_step_two_ranks_init_broadcast_and_collective_skip(tmp_path, mode):
+    """train_step with per-rank data on 2 gloo ranks: the data-dependent ActNorm initialisation is broadcast before the
+    first optimizer step, a non-finite / too large loss on ONE rank makes EVERY rank drop the update (train.py:113-126),
+    parameters stay finite and bit-identical across the replicas (asserted inside the workers)."""
+    out = str(tmp_path / f"s_{mode}.npz")
+    _run(2, out, "_ddp_step_worker.py", mode)
+    r = np.load(out)
+    assert np.isfinite(r["flat"]).all() and np.any(r["bias"] != 0)

@@ -10,6 +10,7 @@ import torch
 from interflow_amd import hip, synth
 from interflow_amd.flow_model import Gaussian, InterpFlow
 from oracle import interflow_oracle as O
+from tests._stress import elementwise_close, noise_aware_close, stress_fixture, stress_state
 
 pytestmark = pytest.mark.gpu
 SCALES = [2, 4]
@@ -33,14 +34,10 @@ def t(a):
 
 
 def rel_close(got, want, tol=RTOL, what=""):
-    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
-    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    assert np.isfinite(got).all(), what
-    scale = max(float(np.abs(want).max()), 1e-30)
-    err = float(np.abs(got - want).max()) / scale
-    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e}"
-    return err
+    """Asserts BOTH the max-norm criterion (|err|max <= tol * |want|max) and the element-wise one
+    (|err_i| <= tol * max(|want_i|, rms(want))), so that a small element cannot be percent-level wrong behind a large
+    one; returns the max-norm figure (tests/_stress.py:elementwise_close returns both)."""
+    return elementwise_close(got, want, tol, what)[0]
 
 
 @pytest.fixture(scope="module")
@@ -235,6 +232,132 @@ def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
             rel_close(out, zw, what=f"step {li} {hw} z"); rel_close(ldo, lw, 2e-4, what=f"step {li} {hw} logdet")
     finally:
         hip.set_conv1_algo(prev)
+
+
+# ----------------------------------------------------------------------------- stress regime (second seed, wide scales)
+@pytest.fixture(scope="module")
+def stress(golden_dir):
+    g = stress_fixture(golden_dir)
+    m = InterpFlow(SCALES)
+    m.load_state_dict({k: t(v) for k, v in stress_state(g).items()}, strict=True)
+    return g, m.eval().to(dev())
+
+
+def _stress_inputs(g, B, H, xs, fs):
+    x = t(synth.synth_images(xs, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(fs, B, H, H, rms=float(g["ft_rms"])).items()}
+    return x, feats
+
+
+@pytest.mark.parametrize("algo", [hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD, hip.CONV1_DIRECT])
+def test_stress_goldens_all_conv1_algorithms(stress, algo):
+    """Reference outputs for a second weight seed with coupling scales spanning ~0.15-0.999 and conditioning features of
+    rms 2 (tests/golden/make_golden_stress.py), 32x32 and 160x160, batch 2, for every form of the bulk convolution.
+      z, logdet (encode) and logdet (decode): against the reference at 1e-4, max-norm AND element-wise.
+      reconstructed x = decode(encode(x)) on the HIP path: against x at 1e-4 max-norm (the reference's own round trip is
+        4.9e-5 max-norm, 8.4e-5 element-wise on this fixture, so the element-wise bound is 2e-4).
+      x decoded from the REFERENCE's z: internal activations reach |z| ~ 50 while x is in [0, 1], so an absolute error that is
+        7e-6 of the flow's dynamic range is 3e-4 of |x|max; float32 itself is at its limit here (the reference's x_rec is 5e-5
+        away from a float64 decode of the same z).  Held to the float64 decode with tests/_stress.py:noise_aware_close
+        (1e-4, or 8x the reference's own float32 noise in that quantity)."""
+    g, model = stress
+    prev = hip.set_conv1_algo(algo)
+    try:
+        for tag, B, H, xs, fs in (("s32", 2, 32, 31, 32), ("s160", 2, 160, 33, 34)):
+            x, feats = _stress_inputs(g, B, H, xs, fs)
+            z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False, )
+            ez = elementwise_close(z, g[f"{tag}_z"], RTOL, f"{tag} z")
+            el = elementwise_close(ld, g[f"{tag}_ld"], RTOL, f"{tag} logdet")
+            noise_aware_close(z, g[f"{tag}_z"], g[f"{tag}_z64"], RTOL, f"{tag} z vs float64")
+            xo, ldo = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+            eo = _errs_pair(xo, x)
+            assert eo[0] <= RTOL and eo[1] <= 2 * RTOL, (tag, eo)
+            elementwise_close(-ldo, ld, RTOL, f"{tag} logdet cancels")
+            xr, ldr = model(t(g[f"{tag}_z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+            ex, nx = noise_aware_close(xr, g[f"{tag}_xr"], g[f"{tag}_xr64"], RTOL, f"{tag} x decoded from the reference's z")
+            elementwise_close(ldr, g[f"{tag}_ldr"], RTOL, f"{tag} logdet rev")
+            print(f"stress {tag} algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  logdet {el[0]:.2e}  "
+                  f"own round trip {eo[0]:.2e} {eo[1]:.2e}  x(ref z) vs float64 {ex[0]:.2e} {ex[1]:.2e} "
+                  f"[reference's own {nx[0]:.2e} {nx[1]:.2e}]")
+    finally:
+        hip.set_conv1_algo(prev)
+
+
+def _errs_pair(got, want):
+    from tests._stress import _errs
+    return _errs(got.detach().cpu().numpy(), want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want))
+
+
+def _check_sampled(v, g, tag, name, tol):
+    stride = int(g["stride"])
+    e = elementwise_close(v.reshape(-1)[::stride], g[f"{tag}_{name}_sample"], tol, f"{tag} {name} sample")
+    s, q = float(v.double().sum()), float(v.double().square().sum())
+    # checksums over all elements: sum of squares to tol, sum to tol relative to the sum of magnitudes
+    assert abs(q / float(g[f"{tag}_{name}_sumsq"]) - 1) <= 2 * tol, (name, q, float(g[f"{tag}_{name}_sumsq"]))
+    assert abs(s - float(g[f"{tag}_{name}_sum"])) <= tol * float(v.double().abs().sum()), (name, s)
+    return e
+
+
+def test_stress_512_reference_fixture_fp32_and_bf16(stress):
+    """BASELINE.json configs[4] size, one 512x512 patch, against the REFERENCE (every 16th element of z and x_rec + float64
+    checksums of all of them): fp32 at the fp32 tolerance, bf16 coupling-network convs at BF16_TOL_*."""
+    g, model = stress
+    B, H = 1, 512
+    x, feats = _stress_inputs(g, B, H, 35, 36)
+    fu = model.flow_upsampler
+    z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+    ez = _check_sampled(z, g, "s512", "z", RTOL)
+    elementwise_close(ld, g["s512_ld"], RTOL, "512 logdet")
+    zs = t(g["s512_z_sample"])
+    xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+    elementwise_close(-ldr, ld, RTOL, "512 logdet cancels")
+    et = _errs_pair(xr, x)                                   # reconstructed x: max-norm 1e-4, element-wise 2e-4 (see above)
+    assert et[0] <= RTOL and et[1] <= 2 * RTOL, et
+    ex = _errs_pair(xr.reshape(-1)[::int(g["stride"])], g["s512_xr_sample"])
+    print(f"stress 512 fp32 (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  decode(encode(x)) vs x {et[0]:.2e} {et[1]:.2e}  "
+          f"vs the reference's own x_rec {ex[0]:.2e} {ex[1]:.2e}")
+    fu.conv_dtype = "bf16"
+    try:
+        zb, ldb = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        stride = int(g["stride"])
+        eb = rel_close_maxnorm(zb.reshape(-1)[::stride], zs, BF16_TOL_Z_STRESS, "bf16 512 z vs reference")
+        rel_close_maxnorm(ldb, g["s512_ld"], BF16_TOL_LD_STRESS, "bf16 512 logdet vs reference")
+        xb, _ = model(zb, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+        er = _errs_pair(xb, x)
+        assert er[0] <= RTOL and er[1] <= 2 * RTOL, er
+        print(f"stress 512 bf16: z vs reference {eb:.2e} (max-norm)  round trip {er[0]:.2e} {er[1]:.2e}")
+    finally:
+        fu.conv_dtype = "fp32"
+
+
+def rel_close_maxnorm(got, want, tol, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape and np.isfinite(got).all(), what
+    err = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e}"
+    return err
+
+
+BF16_TOL_Z_STRESS = 3e-2     # bf16 operands (8 significant bits) in the wide-scale regime, rel. to |z|max
+BF16_TOL_LD_STRESS = 5e-4    # logdet there (measured 1.2e-4; 4.6e-6 on the benign fixture)
+
+
+def test_loss_with_class_zero_matches_oracle(sd_np, model):
+    """calculate_loss when 0 is one of the classes: flow_model.py:143-160 assigns, so a label-0 sample keeps the
+    standard-normal log-density only."""
+    m = InterpFlow([0, 4])
+    m.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+    m = m.eval().to(dev())
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(4, 48, 6, 5, generator=gen)
+    ld = torch.randn(4, generator=gen) * 50
+    label = torch.tensor([0, 4, 0, 4])
+    means = [t(sd_np["mean_shift_0"]), t(sd_np["mean_shift_1"])]
+    covs = [t(sd_np["cov_shift_0"]), t(sd_np["cov_shift_1"])]
+    _, nll_w, _, ib_w = O.calculate_loss(z, ld, 30, label, [0, 4], means, covs)
+    _, nll, _, ib = m.calculate_loss(z.to(dev()), ld.to(dev()), 30, label)
+    rel_close(nll, nll_w, what="nll with class 0"); rel_close(ib, ib_w, 1e-3, what="ll_ib with class 0")
 
 
 def test_batch32_properties(golden_dir, sd_np, model):
@@ -451,7 +574,7 @@ def test_rrdb_encoder_vs_oracle(golden_dir, sd_np, sd, model, B, H, W):
 
 
 # ----------------------------------------------------------------------------- bf16 coupling-network convs (configs[4])
-BF16_TOL_Z, BF16_TOL_LD = 1e-2, 1e-4      # rel. to the tensor's max magnitude (bf16 operands carry 8 significant bits);
+BF16_TOL_Z, BF16_TOL_LD = 1e-2, 1e-4      # rel. to the tensor's max magnitude (max-norm only: bf16 operands carry 8 significant bits);
                                           # measured on MI355X at 160x160: z 3.7e-3, logdet 4.6e-6
 
 
@@ -468,7 +591,7 @@ def test_bf16_conv1_against_reference_and_round_trip(golden_dir, sd_np, model):
     fu.conv_dtype = "bf16"
     try:
         z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
-        e1 = rel_close(z, g["z"], BF16_TOL_Z, what="bf16 z vs reference")
+        e1 = rel_close_maxnorm(z, g["z"], BF16_TOL_Z, what="bf16 z vs reference")
         e2 = rel_close(ld, g["ld"], BF16_TOL_LD, what="bf16 logdet vs reference")
         assert not torch.equal(z, z32), "bf16 path produced the fp32 result: the flag is not reaching the kernel"
         xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
@@ -498,7 +621,7 @@ def test_bf16_512_patch(sd, model):
     fu.conv_dtype = "bf16"
     try:
         z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
-        rel_close(z, z32, BF16_TOL_Z, what="bf16 z vs fp32"); rel_close(ld, ld32, BF16_TOL_LD, what="bf16 logdet vs fp32")
+        rel_close_maxnorm(z, z32, BF16_TOL_Z, what="bf16 z vs fp32"); rel_close(ld, ld32, BF16_TOL_LD, what="bf16 logdet vs fp32")
         xr, _ = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
         rel_close(xr, x, RTOL, what="bf16 512 round trip")
     finally:

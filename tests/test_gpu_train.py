@@ -189,6 +189,48 @@ def test_data_dependent_actnorm_init():
     assert rel(z2, z) < 1e-4 and rel(ld2, ld) < 1e-4
 
 
+def test_actnorm_init_against_reference_fixture(golden_dir):
+    """The REFERENCE's data-dependent ActNorm initialisation (tests/golden/make_golden_stress.py -> aninit_seed0.npz: all 164
+    ActNorms zeroed, train mode, one encode of a 32x32 batch of 4): every bias / logs tensor it wrote, z and logdet; the
+    same through training.init_actnorm.  Tolerance 2e-4 of each tensor's max magnitude (statistics over 1024-16384
+    values in fp32, in another summation order than ATen's CPU mean); see the metric below."""
+    import os
+    from interflow_amd import training
+    g = np.load(os.path.join(golden_dir, "aninit_seed0.npz"))
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    sd0 = {k: (np.zeros_like(v) if k.endswith("actnorm.bias") or k.endswith("actnorm.logs") else v) for k, v in sd_np.items()}
+
+    def fresh():
+        m = InterpFlow(SCALES)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()}, strict=True)
+        return m.train().to(dev())
+    model = fresh()
+    B, H = 4, 32
+    x = torch.from_numpy(synth.synth_images(51, B, H, H)).to(dev())
+    feats = {k: torch.from_numpy(v).to(dev()) for k, v in synth.synth_features(52, B, H, H).items()}
+    z, ld = model.flow_upsampler(gt=x, rrdbResults=feats, logdet=torch.zeros(B, device=dev()), reverse=False, test_input_size=H)
+    assert rel(z, torch.from_numpy(g["z"])) < 1e-4 and rel(ld, torch.from_numpy(g["ld"])) < 1e-4
+    got = model.flow_upsampler.state_dict()
+    # logs: absolute error (a log: = relative error of the scale).  bias: error in units of the standard deviation of the
+    # tensor it is added to, |d bias| * exp(logs) -- some biases are the mean of an already centred tensor (1e-8: rounding
+    # noise in the reference and here), for which an error relative to the bias itself means nothing.
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("p_") and k.endswith(".logs"):
+            kb = k[:-5] + ".bias"
+            dl = (got[k[2:]].cpu() - torch.from_numpy(g[k])).abs().max().item()
+            db = ((got[kb[2:]].cpu() - torch.from_numpy(g[kb])).abs() * torch.exp(torch.from_numpy(g[k]))).max().item()
+            worst = max(worst, dl, db)
+    print("ActNorm init vs reference: worst rel err over 328 tensors %.2e" % worst)
+    assert worst < 2e-4
+    # the explicit helper of the training loop does the same and reports what it initialised
+    model2 = fresh()
+    n = training.init_actnorm(model2, x, x, None, lr_enc=feats)
+    assert n == 164 and training.init_actnorm(model2, x, x, None, lr_enc=feats) == 0
+    got2 = model2.flow_upsampler.state_dict()
+    assert all(torch.equal(got2[k[2:]], got[k[2:]]) for k in g.files if k.startswith("p_"))
+
+
 def test_train_step_harness_learns():
     """interflow_amd.training.train_step (train.py:66-131, NLL + ib): a few Adam iterations on one fixed batch lower the
     loss, parameters of the flow, the prior and the encoder all move, dead parameters do not."""

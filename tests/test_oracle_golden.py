@@ -178,3 +178,65 @@ def test_full160(golden_dir, sd):
     close(z, g["z"], 1e-4, 2e-4); close(ld, g["ld"], 1e-6, 0)
     xr, ldr = O.flow_decode(t(g["z"]), feats, sd, "flow_upsampler.", torch.zeros(B))
     close(xr, g["xr"], 1e-4, 1e-4); close(ldr, g["ldr"], 1e-6, 0)
+
+
+# ----------------------------------------------------------------------------- stress regime + ActNorm initialisation
+def test_stress_fixture_against_oracle(golden_dir):
+    """Second weight seed, coupling scales ~0.15-0.999, feature rms 2 (tests/golden/make_golden_stress.py): the oracle
+    reproduces the reference at 32x32 (full tensors) and 160x160.  Error amplification through the divisions by the scale
+    is real here (the reference's own decode(encode(x)) is off by 4e-5), so the oracle-vs-reference tolerance is wider
+    than on the benign fixtures."""
+    from tests._stress import elementwise_close, stress_fixture, stress_state
+    g = stress_fixture(golden_dir)
+    sd = O.to_torch(stress_state(g))
+    assert float(g["scale_range_22"][0]) < 0.2 and float(g["scale_range_22"][3]) > 0.99
+    for tag, B, H, xs, fs in (("s32", 2, 32, 31, 32), ("s160", 2, 160, 33, 34)):
+        x = t(synth.synth_images(xs, B, H, H))
+        feats = {k: t(v) for k, v in synth.synth_features(fs, B, H, H, rms=float(g["ft_rms"])).items()}
+        z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+        e = elementwise_close(z, g[f"{tag}_z"], 1e-4, f"{tag} z")
+        elementwise_close(ld, g[f"{tag}_ld"], 1e-5, f"{tag} logdet")
+        xr, ldr = O.flow_decode(t(g[f"{tag}_z"]), feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+        e2 = elementwise_close(xr, g[f"{tag}_xr"], 2e-4, f"{tag} x")
+        elementwise_close(ldr, g[f"{tag}_ldr"], 1e-5, f"{tag} logdet rev")
+        print(tag, "oracle vs reference (max-norm, element-wise): z", e, "x", e2)
+
+
+def test_actnorm_init_fixture_against_oracle(golden_dir, sd_np):
+    """The reference's data-dependent ActNorm initialisation (FlowActNorms.py:29-43, flow.py:57-63): all 164 ActNorms zeroed,
+    train mode, one encode of a 32x32 batch of 4 -> every bias / logs tensor, z and logdet."""
+    g = _load(golden_dir, "aninit_seed0.npz")
+    sd0 = {k: (np.zeros_like(v) if k.endswith("actnorm.bias") or k.endswith("actnorm.logs") else v) for k, v in sd_np.items()}
+    sd = {k: v.clone() for k, v in O.to_torch(sd0).items()}
+    B, H = 4, 32
+    x = t(synth.synth_images(51, B, H, H))
+    feats = {k: t(v) for k, v in synth.synth_features(52, B, H, H).items()}
+    with O.training_init():
+        z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+    close(z, g["z"], 1e-4, 1e-4)
+    close(ld, g["ld"], 1e-4, 1e-2)
+    n = 0
+    for k in g.files:
+        if k.startswith("p_"):
+            close(sd["flow_upsampler." + k[2:]], g[k], 2e-4, 2e-4)
+            n += 1
+    assert n == 328
+    # a second pass leaves initialised parameters alone (FlowActNorms.py:33-35)
+    before = {k: v.clone() for k, v in sd.items() if "actnorm" in k}
+    with O.training_init():
+        O.flow_encode(x * 0.5, feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+    assert all(torch.equal(sd[k], v) for k, v in before.items())
+
+
+def test_loss_with_class_zero_assigns_like_the_reference(sd_np):
+    """flow_model.py:143-160 ASSIGNS ll[label == c]; with 0 among the classes a label-0 sample ends with the standard-normal
+    log-density only (the 'X' rows are rewritten by the second loop)."""
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(4, 48, 3, 4, generator=g)
+    ld = torch.randn(4, generator=g)
+    means = [t(sd_np["mean_shift_0"]), t(sd_np["mean_shift_1"])]
+    covs = [t(sd_np["cov_shift_0"]), t(sd_np["cov_shift_1"])]
+    label = torch.tensor([0, 4, 0, 4])
+    _, nll, _, _ = O.calculate_loss(z, ld, 12, label, [0, 4], means, covs)
+    want0 = -(ld[0] + O.gaussian_logp(None, None, z[:1])[0]) / (np.log(2.) * 12)
+    assert abs(float(nll[0] - want0)) < 1e-4 * abs(float(want0))
