@@ -72,7 +72,9 @@ enum {
                                                    [column jc of the 4x4 domain][chunk][k-step][row i][m][MFMA A fragment]  */
     IFL_F_W1A_WINO4 = 19, IFL_F_W1F_WINO4 = 20, /* Winograd F(4x4,3x3) transform (6x6 domain) of the same weights:
                                                    [half of the outputs][3x3 block of positions][sub-chunk of 8 inputs][position][MFMA A fragment] */
-    IFL_F_COUNT = 21
+    IFL_F_W3A_WINO = 21, IFL_F_W3F_WINO = 22,   /* Winograd F(2x2,3x3) transform of the Conv2dZeros weights (rows permuted as W3A / W3F):
+                                                   [row tile][sub-chunk of 16 inputs][position][input quad q][row][4]                        */
+    IFL_F_COUNT = 23
 };
 int64_t ifl_step_param_floats(int C, int has_coupling);
 int64_t ifl_step_field_off(int C, int field);
@@ -147,6 +149,13 @@ int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps);
  * the default at load.  Any other value only queries.
  * Returns the previous setting.  The bf16 variant (IFL_FLOW_BF16_CONV1) always uses the direct form.                */
 int ifl_set_conv1_algo(int algo);
+
+/* Algorithm of the coupling networks' last convolution (flow.Conv2dZeros 3x3, flow.py:67-82) in fp32 (no counterpart in the
+ * reference): 1 = Winograd F(2x2,3x3) minimal filtering (default; 2.25x fewer multiplications, transforms are additions only),
+ * 0 = direct implicit GEMM.  Environment IFL_CONV3_WINO=0/1 sets the default at load.  Any other value only queries.  Returns
+ * the previous setting.  Do not change it between ifl_cond_prepare and the passes that use the prepared workspace (the two
+ * forms lay out fFeatures' log-det partial sums differently).                                                            */
+int ifl_set_conv3_algo(int algo);
 
 /* ---- stand-alone operators on NCHW tensors ---- */
 /* squeeze2d / unsqueeze2d, flow.py:163-193 (pure index permutation, bit-exact). */

@@ -98,6 +98,8 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
         case IFL_F_W1F_WINO: return o.w1w[1];
         case IFL_F_W1A_WINO4: return o.w1x[0];
         case IFL_F_W1F_WINO4: return o.w1x[1];
+        case IFL_F_W3A_WINO: return o.w3w[0];
+        case IFL_F_W3F_WINO: return o.w3w[1];
     }
     return -1;
 }
@@ -150,11 +152,13 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.sf_step = ring * 2 * lv.C;
         lv.sf = take(lv.sf_step * IFL_MAX_COND);
         lv.geom = ifl_choose_geom(lv.H, lv.W);
-        slots += IFL_MAX_COND * lv.geom.ntiles;
+        const int w3 = ifl_w3_slots(lv.C, lv.H, lv.W, 1);
+        lv.ld_step = lv.geom.ntiles > w3 ? lv.geom.ntiles : w3;
+        slots += IFL_MAX_COND * lv.ld_step;
     }
     for (int l = 0; l < IFL_MAX_LEVELS; ++l) {          // fFeatures' sums behind the chain's slots
         w.lv[l].ld_f0 = slots;
-        slots += IFL_MAX_COND * w.lv[l].geom.ntiles;
+        slots += IFL_MAX_COND * w.lv[l].ld_step;
     }
     w.ld_slots = ifl_roundup(slots, 64);
     w.ldpart = take((int64_t)B * w.ld_slots);
@@ -214,6 +218,33 @@ extern "C" int ifl_load_cond(void* ws, int B, int H, int W, int level, const flo
     return load_ft(w.lv[level - 1], B, ft_nchw, (hipStream_t)stream);
 }
 
+// algorithm of the coupling networks' last conv (fp32): 1 = Winograd F(2x2,3x3) (conv3w.hip, default), 0 = direct (conv3.hip)
+static int env_int0(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int& conv3_algo()
+{
+    static int a = [] { int v = env_int0("IFL_CONV3_WINO", 1); return v < 0 || v > 1 ? 1 : v; }();
+    return a;
+}
+
+// fAffine's last conv + the coupling(s) of one step of the chain; advances `slots` by the log-det slots it wrote
+static int chain_conv3(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, const float* sf, int& slots,
+                       int mode, float eps, hipStream_t st)
+{
+    IflStepOff off = ifl_step_off(L.C, 1);
+    int rc;
+    if (conv3_algo() == 1) {
+        IflStepList one{};
+        one.off[0] = L.param_off;
+        rc = ifl_k_conv3w(mode == 0 ? 1 : 2, lv.ha, 0, IFL_HID, const_cast<float*>(sf), 0, lv.z, w.ldpart, w.ld_slots, slots, params, one, 1,
+                          off, w.B, lv.H, lv.W, L.C, eps, st);
+        slots += ifl_w3_slots(L.C, lv.H, lv.W, 0);
+    } else {
+        rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, params + L.param_off, off, lv.geom, w.B, L.C, mode, eps, st);
+        slots += lv.geom.ntiles;
+    }
+    return rc;
+}
+
 // ---- one FlowStep on a level's ringed buffers -------------------------------------------------------------------
 // `slab` is the step's index among the level's conditional steps: its h2 slab holds the conditioning-only part of the first
 // conv (conv1_ft) and its sf slab fFeatures' shift / scale (conv3f); both are written by phase 1.
@@ -233,9 +264,8 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
         { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_ENC, st);
-          rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 0, eps, st); }
+          rc = chain_conv3(L, params, w, lv, sf, slots, 0, eps, st); }
         if (rc) return rc;
-        slots += lv.geom.ntiles;
     }
     return 0;
 }
@@ -259,9 +289,8 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
         { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, prm, off, lv.geom, w.B, L.C, 2, eps, st); }
+          rc = chain_conv3(L, params, w, lv, sf, slots, 2, eps, st); }
         if (rc) return rc;
-        slots += lv.geom.ntiles;
     }
     { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, sf_next, st); }
     if (rc) return rc;
@@ -382,9 +411,16 @@ int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params
           rc = ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st); }
     if (rc) return rc;
     ProfScope ps(IFL_K_CONV3_F, st);
+    if (conv3_algo() == 1)
+        return ifl_k_conv3w(0, h2 + IFL_HID, lv.h2_step, IFL_H2, lv.sf + (int64_t)s0 * lv.sf_step, lv.sf_step, nullptr, w.ldpart,
+                            w.ld_slots, lv.ld_f0 + s0 * ifl_w3_slots(lv.C, lv.H, lv.W, 1), params, steps, nsteps, off, w.B, lv.H, lv.W,
+                            lv.C, eps, st);
     return ifl_k_conv3f(h2, lv.h2_step, lv.sf + (int64_t)s0 * lv.sf_step, lv.sf_step, w.ldpart, w.ld_slots,
                         lv.ld_f0 + s0 * lv.geom.ntiles, params, steps, nsteps, off, lv.geom, w.B, lv.C, eps, st);
 }
+
+// log-det slots per conditional step that fFeatures' kernel of the current algorithm writes
+int f_slots(const IflLevelWs& lv) { return conv3_algo() == 1 ? ifl_w3_slots(lv.C, lv.H, lv.W, 1) : lv.geom.ntiles; }
 
 int n_groups(int B)
 {
@@ -510,7 +546,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
     }
     // fFeatures' sums of log(scale) (phase 1): subtracted by the encode direction, added by the decode direction
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, decode ? 1.0 : -1.0,
-                             w.lv[0].ld_f0, plan.n[0] * w.lv[0].geom.ntiles, w.lv[1].ld_f0, plan.n[1] * w.lv[1].geom.ntiles, B, st);
+                             w.lv[0].ld_f0, plan.n[0] * f_slots(w.lv[0]), w.lv[1].ld_f0, plan.n[1] * f_slots(w.lv[1]), B, st);
 }
 
 int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -567,6 +603,13 @@ extern "C" int ifl_set_conv1_algo(int algo)
 {
     int prev = conv1_algo();
     if (algo >= 0 && algo <= 2) conv1_algo() = algo;
+    return prev;
+}
+
+extern "C" int ifl_set_conv3_algo(int algo)
+{
+    int prev = conv3_algo();
+    if (algo == 0 || algo == 1) conv3_algo() = algo;
     return prev;
 }
 
@@ -665,7 +708,7 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
     if (rc) return rc;
     if ((rc = ifl_k_ring_to_nchw(lv.z, z_out, B, lv.C, lv.H, lv.W, st))) return rc;
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, reverse ? 1.0 : -1.0,
-                             lv.ld_f0, layer->kind == 2 ? lv.geom.ntiles : 0, 0, 0, B, st);
+                             lv.ld_f0, layer->kind == 2 ? f_slots(lv) : 0, 0, 0, B, st);
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------------------------

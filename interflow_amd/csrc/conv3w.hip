@@ -1,0 +1,280 @@
+// conv3w.hip -- the coupling networks' last layer by Winograd F(2x2,3x3) minimal filtering on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32), fused with the affine coupling.  Same operator as conv3.hip (the direct form), 2.25x fewer
+// multiplications, same fp32 arithmetic type; F(2x2,3x3)'s transforms only add / subtract (constants +-1, 1/2 folded into the
+// weights on the host in float64), so its rounding behaviour is that of the direct form.
+//
+// Replaces (reference interflow/models/modules):
+//   flow.Conv2dZeros 3x3 (64 -> 2C for fFeatures, 64 -> C for fAffine): (conv + bias) * exp(3*logs)      flow.py:67-82
+//   shift = h[:,0::2], scale = sigmoid(h[:,1::2] + 2) + eps                                              FlowAffineCouplingsAblation.py:219-240
+//   the affine coupling of both directions and the sums of log(scale)                                      :167-207, 216-217
+//
+//   Y = A^T [ sum_ci U[row][ci] (.) V[ci] ] A,   U = G g G^T (host, float64 -> fp32, pack.py),   V = B^T d B
+// for every 2x2 output tile and its 4x4 input window d; for each of the 16 positions of the transformed domain the sum over the
+// 64 hidden channels is a GEMM  M[row][tile] = U[row][ci] V[ci][tile].
+//
+// Workgroup = one 16 x 16 pixel region of one image x ONE 16-row tile of the output (rows are permuted on the host exactly as
+// for conv3.hip: a lane's four accumulator registers are (shift c, shift c+1, scale c, scale c+1)); 4 waves = the region's four
+// 4 x 16 pixel strips; lane = (tile j of the strip's 2 x 8 tiles, channel quad q).  Per 16-channel sub-chunk:
+//   * the region's 18 x 18 pixel patch of the hidden activations and the row tile's transformed weights are staged in LDS
+//     (prefetched into registers one sub-chunk ahead);
+//   * every lane reads its tile's 4 x 4 window for its 4 channels from the patch, transforms it in registers -- the 16 results
+//     ARE the B operands of its 16 positions -- and multiplies them with the A fragments read from LDS: 64 MFMAs per wave.
+// All 16 positions of a tile sit in one lane's accumulators, so the output transform is register arithmetic and the lane ends
+// with its tile's four pixels in the accumulator layout conv3.hip's epilogue uses.
+// The other row tiles of a network are other workgroups (blockIdx.z): they repeat the staging and the input transform
+// (vector ALU, beside the matrix cores) instead of holding 16 x NT accumulators per lane.
+#include "ifl_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float scale_of(float h, float eps) {
+    return 1.0f / (1.0f + expf(-(h + 2.0f))) + eps;                    // torch.sigmoid(h + 2.) + eps
+}
+
+enum { W3_F = 0, W3_ENC = 1, W3_DEC = 2 };
+
+constexpr int RGN = 16;                       // region edge in pixels
+constexpr int PWD = RGN + 2;                  // patch edge
+constexpr int PPX = PWD * PWD;                // 324 patch pixels
+constexpr int PST = 20;                       // LDS words per patch pixel: 16 channels + 4
+constexpr int PRS = 384;                      // LDS words per patch row (18 x 20 = 360, padded to a multiple of 32): with tiles 2 pixels
+                                              // = 40 words apart and the rows 0 mod 32 words, the 16-byte window reads of a wave's
+                                              // 2 x 8 tiles fall into distinct banks for every lane group of ds_read_b128
+constexpr int NPF = (PPX * 4 + 255) / 256;    // float4 patch loads per thread per sub-chunk (6)
+constexpr int USZ = 16 * 256;                 // floats of one row tile's transformed weights per sub-chunk: [pos][q][row][4]
+
+// B^T x for four values, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+__device__ __forceinline__ void bt4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    const f32x4 t0 = a - c, t1 = b + c, t2 = c - b, t3 = b - d;
+    a = t0; b = t1; c = t2; d = t3;
+}
+
+// src: the 64 hidden channels (pixel stride `pstride` floats) of a ringed channels-last plane; step-dependent pointers are
+// resolved from blockIdx.z by the caller-provided tables (conv3f) or passed directly (chain).
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstride, float* sfAll, int64_t sf_step,
+                   float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots, int slot0,
+                   const float* __restrict__ params, IflStepList steps, int64_t w3w_off, int64_t b3_off, int NT, int NA,
+                   int H, int W, int C, float eps)
+{
+    __shared__ __attribute__((aligned(16))) float patch[PWD * PRS];
+    __shared__ __attribute__((aligned(16))) float us[USZ];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int b = blockIdx.y;
+    const int step = blockIdx.z / NT, rt = blockIdx.z - step * NT;
+    const int gx = (W + RGN - 1) / RGN;
+    const int wgy = blockIdx.x / gx, wgx = blockIdx.x - wgy * gx;
+    const int W2 = W + 2;
+    const float* prm = params + steps.off[step];
+    const float* src = srcAll + (int64_t)step * src_step + (int64_t)b * (H + 2) * W2 * pstride;
+    const float* wsrc = prm + w3w_off + (int64_t)rt * (4 * USZ);
+
+    // ---- staging plan: per-thread source offsets of the patch (same for every sub-chunk) ----
+    int poff[NPF];                            // float offset inside the image's plane, or -1 (outside the ringed plane / past the patch)
+    int pdst[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int idx = tid + k * 256, px = idx >> 2, qd = idx & 3;
+        const int pr = px / PWD, pc = px - pr * PWD;
+        const int gy_ = wgy * RGN + pr, gx_ = wgx * RGN + pc;          // ringed coordinates
+        const bool ok = px < PPX && gy_ <= H + 1 && gx_ <= W + 1;
+        poff[k] = ok ? (gy_ * W2 + gx_) * pstride + qd * 4 : -1;
+        pdst[k] = px < PPX ? pr * PRS + pc * PST + qd * 4 : -1;
+    }
+    f32x4 pre[NPF], upre[4];
+    auto prefetch = [&](int s) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            pre[k] = poff[k] >= 0 ? *(const f32x4*)(src + poff[k] + s * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) upre[k] = *(const f32x4*)(wsrc + s * USZ + (tid + k * 256) * 4);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            if (pdst[k] >= 0) *(f32x4*)&patch[pdst[k]] = pre[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)&us[(tid + k * 256) * 4] = upre[k];
+    };
+
+    // ---- this lane's tile ----
+    const int ty = j >> 3, tx = j & 7;
+    const int py0 = wgy * RGN + 4 * wave + 2 * ty, px0 = wgx * RGN + 2 * tx;              // the tile's pixel (0, 0), plane coordinates
+    const bool wave_live = (wgy * RGN + 4 * wave) < H;                                    // uniform per wave
+    const int wbase = (4 * wave + 2 * ty) * PRS + 2 * tx * PST + 4 * q;                   // window pixel (r, c): + r * PRS + c * PST
+    const int abase = q * 64 + j * 4;                                                     // A fragment of position p: + p * 256
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    prefetch(0);
+    for (int s = 0; s < 4; ++s) {
+        if (s) __syncthreads();               // the previous sub-chunk's LDS reads are over
+        commit();
+        __syncthreads();
+        if (s + 1 < 4) prefetch(s + 1);
+        if (wave_live) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[r][c] = *(const f32x4*)&patch[wbase + r * PRS + c * PST];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bt4(v[0][c], v[1][c], v[2][c], v[3][c]);          // along the rows: v[i][c]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bt4(v[i][0], v[i][1], v[i][2], v[i][3]);          // along the columns: v[i][jc]
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const f32x4 a = *(const f32x4*)&us[abase + p * 256];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[p] = mfma16w(a[e], v[p >> 2][p & 3][e], acc[p]);
+            }
+        }
+    }
+
+    // ---- output transform: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
+    f32x4 y[2][2];
+    {
+        f32x4 t[2][4];
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+            t[0][jc] = acc[jc] + acc[4 + jc] + acc[8 + jc];
+            t[1][jc] = acc[4 + jc] - acc[8 + jc] - acc[12 + jc];
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            y[dy][0] = t[dy][0] + t[dy][1] + t[dy][2];
+            y[dy][1] = t[dy][1] - t[dy][2] - t[dy][3];
+        }
+    }
+
+    // ---- epilogue: bias, exp(3 logs), sigmoid, coupling (as conv3.hip) ----
+    const int Ch = C / 2;
+    const float* b3 = prm + b3_off;
+    const int64_t ring0 = (int64_t)b * (H + 2) * W2;
+    float ld = 0.f;
+    const int sigma = 8 * rt + 2 * q;
+    if (MODE == W3_F) {
+        if (wave_live && sigma < C) {
+            const int c = (sigma + Ch) % C;
+            const f32x4 bF = *(const f32x4*)(b3 + rt * 32 + q * 4), eF = *(const f32x4*)(b3 + rt * 32 + 16 + q * 4);
+            float* sf = sfAll + (int64_t)step * sf_step;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (py0 + dy >= H || px0 + dx >= W) continue;
+                    const int64_t op = ring0 + (int64_t)(py0 + dy + 1) * W2 + px0 + dx + 1;
+                    const f32x4 f = y[dy][dx];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        o[2 * e] = (f[e] + bF[e]) * eF[e];                                        // shift
+                        o[2 * e + 1] = scale_of((f[2 + e] + bF[2 + e]) * eF[2 + e], eps);           // scale
+                        ld += logf(o[2 * e + 1]);
+                    }
+                    *(f32x4*)(sf + op * (2 * C) + 2 * c) = o;
+                }
+        }
+    } else if (wave_live) {
+        const float* sfP = sfAll + (int64_t)step * sf_step;
+        // virtual tile rt: fAffine's coupling on z2 channel pair Ch + sigma (and, encode, fFeatures' on it);
+        // virtual tile NA + rt (encode only): fFeatures' coupling on the pair it covers (z1 channels, or z2 ones past fAffine's tiles)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if (part == 1 && MODE != W3_ENC) break;
+            const int sg = part == 0 ? sigma : 8 * (NA + rt) + 2 * q;
+            const bool vA = part == 0 && sigma < Ch;
+            if (MODE == W3_ENC ? sg >= C : !vA) continue;
+            const int c = MODE == W3_ENC ? (sg + Ch) % C : Ch + sg;
+            f32x4 bA = f32x4{0.f, 0.f, 0.f, 0.f}, eA = bA;
+            if (vA) { bA = *(const f32x4*)(b3 + rt * 32 + q * 4); eA = *(const f32x4*)(b3 + rt * 32 + 16 + q * 4); }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (py0 + dy >= H || px0 + dx >= W) continue;
+                    const int64_t op = ring0 + (int64_t)(py0 + dy + 1) * W2 + px0 + dx + 1;
+                    float* zp = zP + op * C + c;
+                    f32x2 z = *(const f32x2*)zp;
+                    if (vA) {
+                        const f32x4 a = y[dy][dx];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float sh = (a[e] + bA[e]) * eA[e];
+                            const float sc = scale_of((a[2 + e] + bA[2 + e]) * eA[2 + e], eps);
+                            if (MODE == W3_ENC) {
+                                z[e] = z[e] / sc;
+                                z[e] = z[e] - sh;
+                                ld -= logf(sc);
+                            } else {
+                                z[e] = z[e] + sh;
+                                z[e] = z[e] * sc;
+                                ld += logf(sc);
+                            }
+                        }
+                    }
+                    if (MODE == W3_ENC) {
+                        const f32x4 f = *(const f32x4*)(sfP + op * (2 * C) + 2 * c);      // shift c, scale c, shift c+1, scale c+1
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            z[e] = z[e] / f[2 * e + 1];
+                            z[e] = z[e] - f[2 * e];
+                        }
+                    }
+                    *(f32x2*)zp = z;
+                }
+        }
+    }
+    // ---- the workgroup's sum of log(scale) -> its slot: [step][row tile][region] ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ld += __shfl_xor(ld, o, 64);
+    if (lane == 0) red[wave] = ld;
+    __syncthreads();
+    const int nwg = gridDim.x;
+    if (tid == 0)
+        ldpart[(int64_t)b * ld_slots + slot0 + (step * NT + rt) * nwg + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+int ifl_w3_wgs(int H, int W) { return ((H + RGN - 1) / RGN) * ((W + RGN - 1) / RGN); }
+// log-det slots one step writes: fFeatures (f = 1) or the chain's fAffine (f = 0)
+int ifl_w3_slots(int C, int H, int W, int f) { return (f ? ifl_nf(C) : ifl_na(C)) * ifl_w3_wgs(H, W); }
+
+// mode 0: fFeatures for `nsteps` steps (writes sf and its log-det slots [step][row tile][region] from slot0); 1: encode chain;
+// 2: decode chain (nsteps = 1, the step's parameter block in steps.off[0]; ifl_w3_slots(C, H, W, 0) slots from slot0)
+int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, float* sf, int64_t sf_step, float* z,
+                 float* ldpart, int ld_slots, int slot0, const float* params, const IflStepList& steps,
+                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, hipStream_t st)
+{
+    if (nsteps <= 0) return 0;
+    if (C != 12 && C != 48) { ifl_set_error("conv3 (Winograd): C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
+    const int NA = ifl_na(C), NF = ifl_nf(C);
+    const int NT = mode == W3_F ? NF : NA;
+    const int nwg = ifl_w3_wgs(H, W);
+    if ((int64_t)(H + 2) * (W + 2) * pstride >= (int64_t)1 << 31) { ifl_set_error("conv3 (Winograd): plane too large for 32-bit offsets"); return IFL_ENOTSUP; }
+    dim3 grid(nwg, B, nsteps * NT), block(256);
+    const int64_t w3w = off.w3w[mode == W3_F ? 1 : 0], b3 = off.b3[mode == W3_F ? 1 : 0];
+    if (mode == W3_F)
+        hipLaunchKernelGGL((conv3w_kernel<W3_F>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
+                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
+    else if (mode == W3_ENC)
+        hipLaunchKernelGGL((conv3w_kernel<W3_ENC>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
+                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
+    else if (mode == W3_DEC)
+        hipLaunchKernelGGL((conv3w_kernel<W3_DEC>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
+                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
+    else { ifl_set_error("conv3 (Winograd): mode %d", mode); return IFL_EINVAL; }
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

@@ -68,6 +68,7 @@ struct IflStepOff {       // float offsets inside one step's block
     int64_t w1b[2], w2b;      // bf16 copies for the bf16 variant of conv1_ft: first conv over ft (both nets), fFeatures' 1x1
     int64_t w1w[2];           // Winograd F(2x2,3x3) transforms U = G g G^T of the conditioning part of the first conv (both nets)
     int64_t w1x[2];           // Winograd F(4x4,3x3) transforms (6x6 domain) of the same weights
+    int64_t w3w[2];           // Winograd F(2x2,3x3) transforms of the last conv (Conv2dZeros), conv3w.hip: [row tile][sub-chunk][pos][q][row][4]
     int64_t total;
 };
 
@@ -95,7 +96,9 @@ static inline __host__ __device__ IflStepOff ifl_step_off(int C, int has_couplin
         take(4096);
         for (int n = 0; n < 2; ++n) o.w1x[n] = take((int64_t)36 * IFL_HID * IFL_FT);
         take(4096);
-    } else { o.w1b[0] = o.w1b[1] = o.w2b = o.w1w[0] = o.w1w[1] = o.w1x[0] = o.w1x[1] = 0; }
+        o.w3w[0] = take((int64_t)ifl_na(C) * 16 * 16 * IFL_HID);
+        o.w3w[1] = take((int64_t)ifl_nf(C) * 16 * 16 * IFL_HID);
+    } else { o.w1b[0] = o.w1b[1] = o.w2b = o.w1w[0] = o.w1w[1] = o.w1x[0] = o.w1x[1] = o.w3w[0] = o.w3w[1] = 0; }
     o.total = p;
     return o;
 }
@@ -137,6 +140,7 @@ struct IflLevelWs {
     float* sf;                // [IFL_MAX_COND][B][H+2][W+2][2C]  fFeatures' (shift c, scale c) pairs of every conditional step
     int64_t h2_step, sf_step; // floats per step slab
     int ld_f0;                // first ldpart slot of this level's fFeatures sums: [step][tile]
+    int ld_step;              // slots reserved per conditional step (the larger of the direct kernels' tiles and conv3w's regions x row tiles)
     IflGeom geom;
 };
 
@@ -215,3 +219,9 @@ int ifl_k_conv3f(const float* h2all, int64_t h2_step, float* sfall, int64_t sf_s
                  const float* params, const IflStepList& steps, int nsteps, const IflStepOff& off, const IflGeom& g, int B, int C,
                  float eps, hipStream_t st);
 int ifl_k_fapply(const float* sf, float* z, int B, int C, int H, int W, hipStream_t st);
+// conv3w.hip: the same operators by Winograd F(2x2,3x3); mode 0 = fFeatures (nsteps steps), 1 = encode chain, 2 = decode chain
+int ifl_w3_wgs(int H, int W);
+int ifl_w3_slots(int C, int H, int W, int f);
+int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, float* sf, int64_t sf_step, float* z,
+                 float* ldpart, int ld_slots, int slot0, const float* params, const IflStepList& steps,
+                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, hipStream_t st);

@@ -22,7 +22,7 @@ FLOW_BF16_CONV1 = 2
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
  F_W3A, F_W3F, F_B3A, F_B3F, F_W1A_BF16, F_W1F_BF16, F_W2F_BF16, F_W1A_WINO, F_W1F_WINO,
- F_W1A_WINO4, F_W1F_WINO4) = range(21)
+ F_W1A_WINO4, F_W1F_WINO4, F_W3A_WINO, F_W3F_WINO) = range(23)
 
 
 class IflLayer(Structure):
@@ -108,6 +108,8 @@ def lib():
     L.ifl_set_schedule.restype = c_int
     L.ifl_set_conv1_algo.argtypes = [c_int]
     L.ifl_set_conv1_algo.restype = c_int
+    L.ifl_set_conv3_algo.argtypes = [c_int]
+    L.ifl_set_conv3_algo.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -125,7 +127,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
-           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static")
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 
@@ -142,6 +144,15 @@ def set_conv1_algo(algo: int = -1) -> int:
     """Algorithm of the fp32 bulk convolution (ifl_set_conv1_algo): CONV1_WINOGRAD4 (F(4x4,3x3), default), CONV1_WINOGRAD
     (F(2x2,3x3)) or CONV1_DIRECT; any other value only queries.  Returns the previous setting."""
     return int(lib().ifl_set_conv1_algo(algo))
+
+
+CONV3_DIRECT, CONV3_WINOGRAD = 0, 1
+
+
+def set_conv3_algo(algo: int = -1) -> int:
+    """Algorithm of the coupling networks' last convolution (ifl_set_conv3_algo): CONV3_WINOGRAD (F(2x2,3x3), default) or
+    CONV3_DIRECT; any other value only queries.  Returns the previous setting."""
+    return int(lib().ifl_set_conv3_algo(algo))
 
 
 def prof_enable(kernel_ids=()):
@@ -289,7 +300,7 @@ def gaussian_logp_static(z: torch.Tensor, out: torch.Tensor, mean=None, cov_inv=
     with torch.cuda.device(z.device):
         check(lib().ifl_gaussian_logp_static(_ptr(z), _ptr(mean) if cov_inv is not None else c_void_p(0), _ptr(cov_inv),
                                              float(logdet_cov), _ptr(out), B, C, H, W, _stream()),
-              "ifl_gaussian_logp_static")
+              "ifl_gaussian_logp_static", "ifl_set_conv3_algo")
     return out
 
 

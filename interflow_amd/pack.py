@@ -160,6 +160,20 @@ def _pack_conv3(w3, bias, logs, C, net):
     return wp, bp.reshape(-1).astype(F32)
 
 
+def _pack_conv3_wino(w3, C, net):
+    """Conv2dZeros weight [rows, 64, 3, 3] -> Winograd F(2x2,3x3) domain U = G g G^T (4x4 positions; float64, rounded once to
+    fp32) with the rows permuted as `_pack_conv3` does, laid out [row tile][s][pos][q][i][e]: position pos = 4 i_pos + jc,
+    row i of the tile, in channel 16 s + 4 q + e (conv3w.hip: one contiguous 16 KB slab per (row tile, sub-chunk))."""
+    rows = _row_map(C, net)
+    ntile = rows.shape[0]
+    flat = rows.reshape(ntile, 16)
+    g = np.concatenate([w3.astype(np.float64), np.zeros((1, HIDDEN, 3, 3))])     # -1 picks the zero row
+    u = np.einsum("ia,ocab,jb->ocij", _WINO_G, g, _WINO_G).astype(F32)           # [rows + 1, 64, 4, 4]
+    u = u[flat]                                                                   # [tile][i 16][64][4][4]
+    u = u.reshape(ntile, 16, 4, 4, 4, 16)                                        # tile i s q e pos
+    return np.ascontiguousarray(u.transpose(0, 2, 5, 3, 1, 4)).reshape(-1)
+
+
 def pack_step(prm, pfx, C, has_coupling, out, training=False):
     """Fill `out` (float32 view of the step's block).  Returns (sum_logs, sum_log_s)."""
     L = hip.lib()
@@ -194,6 +208,7 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
                                  prm[q + "4.logs"].astype(F32), C, net)
             put(fw3, wp)
             put(fb3, bp)
+            put(hip.F_W3A_WINO if net == 0 else hip.F_W3F_WINO, _pack_conv3_wino(prm[q + "4.weight"].astype(F32), C, net))
             put(hip.F_W1A_BF16 if net == 0 else hip.F_W1F_BF16,
                 _pack_conv1_bf16(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0))
             put(hip.F_W1A_WINO if net == 0 else hip.F_W1F_WINO,

@@ -234,6 +234,46 @@ def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
         hip.set_conv1_algo(prev)
 
 
+@pytest.mark.parametrize("algo", [hip.CONV3_DIRECT, hip.CONV3_WINOGRAD])
+def test_conv3_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
+    """Both forms of the coupling networks' last convolution (direct, Winograd F(2x2,3x3): conv3w.hip) against the reference's
+    outputs: the 160x160 fixture, an image whose planes have odd sizes (20x36 -> 10x18 and 5x9: regions and tiles overhang the
+    plane), single steps on ragged planes against the oracle, both directions."""
+    prev = hip.set_conv3_algo(algo)
+    try:
+        assert hip.set_conv3_algo(-1) == algo
+        g = load(golden_dir, "full160_seed0.npz", sd_np)
+        B, H = 2, 160
+        x = t(synth.synth_images(1, B, H, H)).to(dev())
+        feats = {k: t(v).to(dev()) for k, v in synth.synth_features(2, B, H, H).items()}
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        e1 = rel_close(z, g["z"], what="z"); e2 = rel_close(ld, g["ld"], what="logdet")
+        xr, ldr = model(t(g["z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        e3 = rel_close(xr, g["xr"], what="x"); rel_close(ldr, g["ldr"], what="logdet rev")
+        print(f"conv3 algo {algo}: rel errs z {e1:.2e} logdet {e2:.2e} x {e3:.2e}")
+        g = load(golden_dir, "stack32_seed0.npz", sd_np)
+        fu = model.flow_upsampler
+        x = t(synth.synth_images(13, 1, 20, 36)).to(dev())
+        feats = {k: t(v).to(dev()) for k, v in synth.synth_features(14, 1, 20, 36).items()}
+        z, ld = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+        rel_close(z, g["odd_z"], what="odd z"); rel_close(ld, g["odd_ld"], what="odd logdet")
+        xr, ldr = fu(z=t(g["odd_z"]).to(dev()), rrdbResults=feats, logdet=0., reverse=True)
+        rel_close(xr, g["odd_xr"], what="odd x"); rel_close(ldr, g["odd_ldr"], what="odd logdet rev")
+        for li, hw in ((22, (1, 1)), (5, (3, 5)), (30, (7, 2)), (3, (17, 33)), (22, (16, 16)), (30, (19, 5))):
+            step = fu.layers[li]
+            gen = torch.Generator().manual_seed(li + hw[0])
+            zz = torch.randn(2, step.in_channels, *hw, generator=gen)
+            ft = torch.randn(2, 320, *hw, generator=gen)
+            l0 = torch.randn(2, generator=gen)
+            for rev in (False, True):
+                zw, lw = O.flow_step(zz, l0, rev, ft, sd, f"flow_upsampler.layers.{li}.")
+                out, ldo = step(zz.to(dev()), l0.to(dev()), reverse=rev, rrdbResults=ft.to(dev()))
+                rel_close(out, zw, what=f"step {li} {hw} rev={rev} z")
+                rel_close(ldo - l0.to(dev()), lw - l0, 2e-4, what=f"step {li} {hw} rev={rev} dlogdet")
+    finally:
+        hip.set_conv3_algo(prev)
+
+
 # ----------------------------------------------------------------------------- stress regime (second seed, wide scales)
 @pytest.fixture(scope="module")
 def stress(golden_dir):

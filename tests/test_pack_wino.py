@@ -63,6 +63,31 @@ def test_step_block_has_room_for_every_field():
     L = _lib_or_skip()
     for C in (12, 48):
         total = L.ifl_step_param_floats(C, 1)
-        offs = sorted(L.ifl_step_field_off(C, f) for f in range(hip.F_W1F_WINO4 + 1))
-        assert offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:])) and offs[-1] + 36 * 64 * 320 <= total
-        assert L.ifl_step_field_off(C, hip.F_W1F_WINO4 + 1) == -1
+        offs = sorted(L.ifl_step_field_off(C, f) for f in range(hip.F_W3F_WINO + 1))
+        nf = -(-C // 8)
+        assert offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:])) and offs[-1] + nf * 16 * 16 * 64 <= total
+        assert L.ifl_step_field_off(C, hip.F_W3F_WINO) == offs[-1]
+        assert L.ifl_step_field_off(C, hip.F_W3F_WINO + 1) == -1
+
+
+def test_conv3_winograd_weights_reproduce_the_direct_convolution():
+    """pack._pack_conv3_wino: U = G g G^T of the permuted Conv2dZeros rows.  Evaluating F(2x2,3x3) from the packed block with
+    numpy (V = B^T d B, M = U (.) V summed over channels, Y = A^T M A) gives the direct 3x3 correlation of the same rows."""
+    from interflow_amd import pack
+    rng = np.random.default_rng(3)
+    C = 12
+    w3 = rng.standard_normal((2 * C, 64, 3, 3)).astype(np.float32)
+    up = pack._pack_conv3_wino(w3, C, 1).reshape(2, 4, 16, 4, 16, 4)          # tile s pos q i e
+    rows = pack._row_map(C, 1).reshape(2, 16)
+    d = rng.standard_normal((64, 4, 4))
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    V = np.einsum("ir,crk,jk->cij", BT, d, BT).reshape(64, 16)
+    for tile in range(2):
+        U = up[tile].transpose(1, 3, 0, 2, 4).reshape(16, 16, 64)             # pos i ch(s q e)
+        M = np.einsum("pic,cp->ip", U.astype(np.float64), V).reshape(16, 4, 4)
+        Y = np.einsum("ai,rij,bj->rab", AT, M, AT)                            # [row i][2][2]
+        for i in range(16):
+            r = rows[tile, i]
+            want = np.zeros((2, 2)) if r < 0 else np.array([[np.sum(w3[r].astype(np.float64) * d[:, y:y + 3, x:x + 3]) for x in range(2)] for y in range(2)])
+            np.testing.assert_allclose(Y[i], want, rtol=1e-5, atol=1e-5)
