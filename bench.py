@@ -190,6 +190,7 @@ def main():
             hip.set_schedule(aux_stream=1, groups=2)
 
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    ranks = shard.rank_devices(dist, dev)
 
     if rank == 0:
         patches = world * B * args.steps
@@ -229,7 +230,8 @@ def main():
             "config": {"workload": f"InterFlow flow encode+decode, batch {B} of 160x160 RGB patches per GPU, fp32, "
                                    "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
                                    "add_gt_noise=False (BASELINE.json configs[1])",
-                       "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)"},
+                       "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)",
+                       "world_size": dist.get_world_size() if dist is not None else 1, "ranks": ranks},
             "roofline": {"bound": "mfma",
                          "kernel": kname + " (both coupling networks' first 3x3 conv over the 320 conditioning "
                                    "channels + fFeatures' 1x1, level 1, %d conditional steps per launch)" % round(32 * args.steps / max(n1, 1)),

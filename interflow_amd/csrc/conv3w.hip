@@ -56,7 +56,7 @@ __device__ __forceinline__ void bt4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
 // src: the 64 hidden channels (pixel stride `pstride` floats) of a ringed channels-last plane; step-dependent pointers are
 // resolved from blockIdx.z by the caller-provided tables (conv3f) or passed directly (chain).
 template <int MODE>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 3)
 void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstride, float* sfAll, int64_t sf_step,
                    float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots, int slot0,
                    const float* __restrict__ params, IflStepList steps, int64_t w3w_off, int64_t b3_off, int NT, int NA,

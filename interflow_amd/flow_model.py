@@ -3,8 +3,8 @@
 
 `InterpFlow.forward` / `interpolate_image` / `weighted_interpolate_image` / `calculate_loss` / `get_pdf`
 run the flow, the latent prior and the latent interpolation through libinterflow_hip.so.  The
-conditioning encoder (`RRDBNet`, outside the hot path: SURVEY.md section 8(f) row 1) runs on stock
-PyTorch-ROCm ops.
+conditioning encoder (`RRDBNet`) runs through `ifl_rrdb_encode` (inference) or, when autograd
+must reach its parameters, through the differentiable HIP convolution; there is no eager-PyTorch or CPU evaluation.
 """
 from __future__ import annotations
 
@@ -129,32 +129,13 @@ class RRDBNet(nn.Module):
         return out
 
     def forward(self, x, get_steps=False):
-        if x.is_cuda and x.dtype == torch.float32:
-            return self._forward_hipconv(x, get_steps)
-        x = self.space2depth(x, 4)
-        fea = self.conv_first(x)
-        block_idxs = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []
-        block_results = {}
-        for idx, m in enumerate(self.RRDB_trunk.children()):
-            fea = m(fea)
-            if idx in block_idxs:
-                block_results["block_{}".format(idx)] = fea
-        last_lr_fea = fea + self.trunk_conv(fea)
-        # :77,105-109 -- the reference's LeakyReLU is inplace, so the tensors it returns under 'fea_up2' and
-        # 'fea_up4' hold the POST-activation values; reproduced here.
-        fea_up2 = F.leaky_relu(self.upconv1(F.interpolate(last_lr_fea, scale_factor=2, mode='nearest')), 0.2)
-        fea_up4 = F.leaky_relu(self.upconv2(F.interpolate(fea_up2, scale_factor=2, mode='nearest')), 0.2)
-        out = self.conv_last(F.leaky_relu(self.HRconv(fea_up4), 0.2))
-        results = {'last_lr_fea': last_lr_fea, 'fea_up1': last_lr_fea, 'fea_up2': fea_up2, 'fea_up4': fea_up4,
-                   'fea_up8': None, 'fea_up16': None, 'fea_up32': None, 'out': out}
-        if opt_get(self.opt, ['network_G', 'flow', 'fea_up0']) or False:
-            results['fea_up0'] = F.interpolate(last_lr_fea, scale_factor=1 / 2, mode='bilinear')
-        if opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False:
-            results['fea_up-1'] = F.interpolate(last_lr_fea, scale_factor=1 / 4, mode='bilinear')
-        if get_steps:
-            results.update(block_results)
-            return results
-        return out
+        """RRDBNet_arch.py:85-148 with autograd: every convolution on the HIP kernels (`_forward_hipconv`).  There is no
+        eager-PyTorch / CPU evaluation of the encoder in this package: other devices and dtypes raise."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+            raise hip.InterflowHipError(
+                f"RRDBNet.forward: expected a float32 GPU tensor, got {getattr(x, 'dtype', type(x))} on "
+                f"{getattr(x, 'device', '?')}; the HIP path has no CPU or other-dtype fallback")
+        return self._forward_hipconv(x, get_steps)
 
 
 class RRDBGlowNet(nn.Module):
@@ -250,7 +231,7 @@ class RRDBGlowNet(nn.Module):
         upn1 = opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False
         if not self._needs_autograd() and concat_on and not upn1:
             return self._rrdb_hip(lr)
-        # training of the encoder (autograd) still runs on PyTorch-ROCm ops: the backward kernels are not built yet
+        # autograd has to reach the encoder's parameters: the differentiable evaluation (every convolution on the HIP kernels)
         if not lr.is_cuda:
             raise hip.InterflowHipError(f"rrdbPreprocessing: tensor is on {lr.device}; there is no CPU path")
         rrdbResults = self.RRDB(lr, get_steps=True)

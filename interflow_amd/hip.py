@@ -300,7 +300,7 @@ def gaussian_logp_static(z: torch.Tensor, out: torch.Tensor, mean=None, cov_inv=
     with torch.cuda.device(z.device):
         check(lib().ifl_gaussian_logp_static(_ptr(z), _ptr(mean) if cov_inv is not None else c_void_p(0), _ptr(cov_inv),
                                              float(logdet_cov), _ptr(out), B, C, H, W, _stream()),
-              "ifl_gaussian_logp_static", "ifl_set_conv3_algo")
+              "ifl_gaussian_logp_static")
     return out
 
 

@@ -68,6 +68,18 @@ def max_over_ranks(value: float, dist, device="cpu") -> float:
     return float(t.item())
 
 
+def rank_devices(dist, device) -> list:
+    """[{rank, device, name}] of every rank (benchmarks record it, so a scaling run shows which GPUs it really used)."""
+    dev = torch.device(device)
+    me = {"rank": dist_env()[0], "device": str(dev),
+          "name": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"}
+    if dist is None:
+        return [me]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, me)
+    return sorted(parts, key=lambda d: d["rank"])
+
+
 def run_sharded(units: Sequence, process: Callable[[Sequence], Sequence], batch: int, rank: int, world: int):
     """Run `process` over this rank's slice of `units` in batches of at most `batch`; returns [(unit index, result)].
     `process(list of units) -> list of results`, one per unit."""

@@ -274,6 +274,28 @@ def test_conv3_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
         hip.set_conv3_algo(prev)
 
 
+def test_integration_md_ctypes_stub_runs_verbatim(golden_dir, sd_np, model):
+    """the ctypes stub a maintainer of the reference would add, executed as printed (the code block is
+    read from the file) around a module with the reference's layout (`.layers`, `.output_shapes`, layer class names), against
+    the reference's 32x32 stack outputs."""
+    import re
+    root = os.path.dirname(golden_dir.rstrip("/")).rsplit("/tests", 1)[0]
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class HipFlow" in b]
+    assert len(blocks) == 1
+    ns = {}
+    exec(blocks[0], ns)
+    g = load(golden_dir, "stack32_seed0.npz", sd_np)
+    B, H = 2, 32
+    x = t(synth.synth_images(11, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(12, B, H, H).items()}
+    flow = ns["HipFlow"](model.flow_upsampler)
+    z, ld = flow.run(x, feats, torch.zeros(B, device=dev()), reverse=False)
+    rel_close(z, g["tis_z"], what="stub z"); rel_close(ld, g["tis_ld"], what="stub logdet")
+    xr, ldr = flow.run(t(g["tis_z"]).to(dev()), feats, torch.zeros(B, device=dev()), reverse=True)
+    rel_close(xr, g["tis_xr"], what="stub x"); rel_close(ldr, g["tis_ldr"], what="stub logdet rev")
+
+
 # ----------------------------------------------------------------------------- stress regime (second seed, wide scales)
 @pytest.fixture(scope="module")
 def stress(golden_dir):

@@ -126,3 +126,16 @@ def test_winograd_weight_transform_reproduces_the_direct_convolution():
             T = np.stack([M[0] + M[1] + M[2], M[1] - M[2] - M[3]])
             out[2 * tr:2 * tr + 2, 2 * tc:2 * tc + 2] = np.stack([T[:, 0] + T[:, 1] + T[:, 2], T[:, 1] - T[:, 2] - T[:, 3]], axis=1)
     assert np.abs(out[:H, :W] - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_encoder_has_no_eager_cpu_path():
+    """RRDBNet.forward on a CPU tensor raises instead of evaluating with eager PyTorch ops (no fallback)."""
+    import pytest
+    import torch
+    from interflow_amd import hip
+    from interflow_amd.flow_model import RRDBNet
+    net = RRDBNet(3, 3, 64, 1, opt={"network_G": {"flow": {"stackRRDB": {"blocks": [0]}}}})
+    with pytest.raises(hip.InterflowHipError):
+        net(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(hip.InterflowHipError):
+        net(torch.zeros(1, 3, 8, 8, dtype=torch.float64))

@@ -69,10 +69,12 @@ def main():
     loss = nll.mean() - ll_ib.mean()
     red.zero_grad(); loss.backward(); red.finish(); t.append(sync())
     opt.step(); t.append(sync())
+    ranks = shard.rank_devices(dist, dev)
     if rank == 0:
         print(json.dumps({"workload": f"training step (NLL + ib; forward, backward, Adam), batch {B} of {P}x{P} per GPU, fp32, "
                                       f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained'}{', with LR-consistency term' if args.consistency else ''}",
-                          "n_gpus": world, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                          "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
+                          "ranks": ranks, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                           "patches_per_s": B * world * args.steps / dt, "last": out,
                           "split_ms": {"encoder_fwd": (t[1] - t[0]) * 1e3, "flow_fwd_loss": (t[2] - t[1]) * 1e3,
                                        "backward_allreduce": (t[3] - t[2]) * 1e3, "adam": (t[4] - t[3]) * 1e3}}), flush=True)
