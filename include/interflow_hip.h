@@ -216,6 +216,29 @@ int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream);
 int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin, const float* dy, int dy_stride, int dy_off, int cout,
                      float* dW, int cin_total, int ci0, int taps, int B, int h, int w, void* stream);
 
+/* ---- per-pixel operators of the coupling networks for the training path, forward and backward (train_glue.hip) ----
+ * ifl_an_relu_*: y = relu((x + bias) * exp(logs)) on ringed channels-last planes [B][h+2][w+2][64] (flow.Conv2d's ActNorm,
+ * flow.py:60-64 / FlowActNorms.py:87-92, and the ReLU behind it, FlowAffineCouplingsAblation.py:250,252); only interior pixels
+ * are read and written.  The backward writes dx and per-block partial sums partials[ifl_an_relu_blocks()][128]: [0:64] of
+ * d bias, [64:128] of d logs (the caller adds the blocks).
+ * ifl_coupling_*: the affine coupling of FlowAffineCouplingsAblation.py:167-207 on channels [c0, c0+n) of a contiguous
+ * channels-last z [B][h][w][C] (other channels copied): hs = h * exp(3 logs3) (flow.py:80-82), shift = hs[2i], scale =
+ * sigmoid(hs[2i+1] + 2) + eps (:229), h = the raw Conv2dZeros output (conv + bias) in a ringed buffer of `hstride` channels.
+ * branch 0: z' = (z + shift) * scale, logdet += sum log scale; branch 1: z' = z / scale - shift, logdet -= sum log scale.
+ * ldpart[B][ifl_coupling_blocks()] receives the signed per-block sums.  The backward takes d z', d logdet [B] (or NULL) and
+ * writes d z, d h (interior pixels, rows [0, 2n); the buffer's other entries must be zero) and
+ * dlogs_part[B * ifl_coupling_blocks()][2n], the per-block sums of d logs3.                                              */
+int64_t ifl_an_relu_blocks(int B, int h, int w);
+int ifl_an_relu_fwd(const float* x, float* y, const float* bias, const float* logs, int B, int h, int w, int C, void* stream);
+int ifl_an_relu_bwd(const float* x, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
+                    int B, int h, int w, int C, void* stream);
+int ifl_coupling_blocks(int h, int w);
+int ifl_coupling_fwd(const float* z, float* zout, const float* h_ring, int hstride, const float* logs3, float eps, int branch,
+                     int c0, int n, float* ldpart, int B, int h, int w, int C, void* stream);
+int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
+                     float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, int B, int h, int w,
+                     int C, void* stream);
+
 /* ---- conditioning encoder ----
  * RRDBNet.forward(get_steps=True) (RRDBNet_arch.py:85-148) followed by RRDBGlowNet.rrdbPreprocessing
  * (RRDBGlowNet_arch.py:217-246) for the shipped options (scale 4, nf 64, gc 32, stackRRDB concat): x [B,3,H,W] ->

@@ -757,6 +757,8 @@ extern "C" int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin
     IFL_CHECK_ARG(x && dy && dW, IFL_EINVAL, "null pointer");
     IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape B=%d h=%d w=%d", B, h, w);
     IFL_CHECK_ARG(ci0 >= 0 && (ci0 * 32 + cin) <= cin_total, IFL_EINVAL, "channel range outside dW");
+    IFL_CHECK_ARG(x_stride % 4 == 0 && x_off % 4 == 0 && dy_stride % 4 == 0 && dy_off % 4 == 0, IFL_EINVAL,
+                  "strides and offsets must be multiples of 4 (16-byte loads)");
     return ifl_k_wgrad(x, x_stride, x_off, cin, dy, dy_stride, dy_off, cout, dW, cin_total, ci0, taps, ifl_choose_geom(h, w), B,
                        (hipStream_t)stream);
 }

@@ -181,11 +181,15 @@ void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __
                   float* __restrict__ dW, int cin_total, int ci0, IflGeom g, int B)
 {
     constexpr int NP = CT * TAPS, PPW = (NP + 3) / 4;            // pairs, pairs per wave
-    constexpr int DS = CT * 32 + 1;                               // dY row stride in LDS (odd: conflict-free column reads)
-    constexpr int XS = 33;
-    __shared__ float dy[IFL_MT * DS];
-    __shared__ float xp[IFL_PP_MAX * XS];
+    constexpr int DS = CT * 32;                                   // dY row stride in LDS: the 32 lanes of a half-wave read consecutive words
+    constexpr int XS = 32;
+    constexpr int NDY = IFL_MT * CT * 8 / 256;                    // float4 loads per thread: dY tile (4 CT)
+    constexpr int NXP = (IFL_PP_MAX * 8 + 255) / 256;             // ... and X patch (10)
+    constexpr int NDYF = IFL_MT * DS, NXPF = NXP * 32 * XS, NTF = 32 * 32 * TAPS;
+    __shared__ __attribute__((aligned(16))) float smem[NDYF + NXPF > NTF ? NDYF + NXPF : NTF];
     __shared__ int pos[IFL_MT];
+    float* dy = smem;                                             // [128 px][cout]
+    float* xp = smem + NDYF;                                      // [patch px][32 ch]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -199,30 +203,59 @@ void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    const int nwork = g.ntiles * B;
-    for (int wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+    // staging through registers, one work item ahead: the loads of tile k + 1 travel while tile k is multiplied
+    f32x4 rdy[NDY], rxp[NXP];
+    int rpos[NDY];
+    IflTile t{};
+    auto fetch = [&](int wk) {
         const int b = wk / g.ntiles;
-        const IflTile t = ifl_tile(g, wk - b * g.ntiles);
-        if (!t.active) continue;
+        t = ifl_tile(g, wk - b * g.ntiles);
+        const float* dyb = DY + (int64_t)b * plane * dys + dyoff;
+        const float* xb = X + (int64_t)b * plane * xs + xoff + chunk * 32;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int idx = tid + k * 256, p = idx / (CT * 8), c4 = idx - p * (CT * 8);
+            const int pi = t.s + p;
+            rdy[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rpos[k] = 0;
+            if (t.active && pi < t.npx) {
+                const int ty = pi / t.bwb, tx = pi - ty * t.bwb;
+                rdy[k] = *(const f32x4*)(dyb + ((int64_t)(ty + 1) * W2 + t.x0 + tx + 1) * dys + c4 * 4);
+                rpos[k] = (ty - t.y_first - (TAPS == 9 ? 1 : 0)) * t.PW + tx + (TAPS == 9 ? 0 : 1);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, c4 = idx & 7;
+            rxp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t.active && p < t.PP) {
+                const int r = p / t.PW, cc = p - r * t.PW;
+                rxp[k] = *(const f32x4*)(xb + ((int64_t)(t.y_first + 1 + r) * W2 + t.x0 + cc) * xs + c4 * 4);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int idx = tid + k * 256, p = idx / (CT * 8), c4 = idx - p * (CT * 8);
+            *(f32x4*)&dy[p * DS + c4 * 4] = rdy[k];
+            if (c4 == 0) pos[p] = rpos[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) *(f32x4*)&xp[(tid + k * 256) * 4] = rxp[k];
+    };
+
+    const int nwork = g.ntiles * B;
+    int wk = blockIdx.x;
+    if (wk < nwork) fetch(wk);
+    for (; wk < nwork; wk += gridDim.x) {
+        const int PW = t.PW;
+        const bool active = t.active;
         __syncthreads();                                          // previous tile fully consumed
-        // stage dY rows of the tile (zero for pixels past the band's end), their patch positions, and the X patch
-        for (int idx = tid; idx < IFL_MT * CT * 32; idx += 256) {
-            int p = idx / (CT * 32), c = idx - p * (CT * 32);
-            int pi = t.s + p;
-            float v = 0.f;
-            if (pi < t.npx) {
-                int ty = pi / t.bwb, tx = pi - ty * t.bwb;
-                v = DY[((int64_t)b * plane + (int64_t)(ty + 1) * W2 + t.x0 + tx + 1) * dys + dyoff + c];
-                if (c == 0) pos[p] = (ty - t.y_first - (TAPS == 9 ? 1 : 0)) * t.PW + tx + (TAPS == 9 ? 0 : 1);
-            } else if (c == 0) pos[p] = 0;
-            dy[p * DS + c] = v;
-        }
-        for (int idx = tid; idx < t.PP * 32; idx += 256) {
-            int p = idx >> 5, c = idx & 31;
-            int r = p / t.PW, cc = p - r * t.PW;
-            xp[p * XS + c] = X[((int64_t)b * plane + (int64_t)(t.y_first + 1 + r) * W2 + t.x0 + cc) * xs + xoff + chunk * 32 + c];
-        }
+        commit();
         __syncthreads();
+        if (wk + (int)gridDim.x < nwork) fetch(wk + gridDim.x);
+        if (!active) continue;
 #pragma unroll 4
         for (int kk = 0; kk < IFL_MT / 2; ++kk) {
             const int p = 2 * kk + h;
@@ -232,22 +265,33 @@ void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __
                 const int pr = wave + 4 * q;
                 if (pr < NP) {                                   // wave-uniform
                     const int ct = pr / TAPS, tap = pr - ct * TAPS;
-                    const int tapoff = TAPS == 9 ? (tap / 3) * t.PW + (tap % 3) : 0;
+                    const int tapoff = TAPS == 9 ? (tap / 3) * PW + (tap % 3) : 0;
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy[p * DS + ct * 32 + j], xp[(pp + tapoff) * XS + j], acc[q], 0, 0, 0);
                 }
             }
         }
     }
-    // flush: accumulator element r of lane (j, h) is dW[co = ct*32 + (r&3) + 8*(r>>2) + 4*h][ci = chunk*32 + j][tap]
+    // flush: accumulator element r of lane (j, h) is dW[co = ct*32 + (r&3) + 8*(r>>2) + 4*h][ci = chunk*32 + j][tap].  For a
+    // fixed co the chunk's (ci, tap) are 32 * TAPS contiguous floats of dW, so each 32-row block of the accumulators goes through
+    // LDS as T[co][ci][tap] and is added with coalesced float atomics (a lane-per-ci flush scatters every wave instruction over
+    // 64 cache lines, which is an order of magnitude slower at the memory side).
+    for (int ct = 0; ct < CT; ++ct) {
+        __syncthreads();                                          // the main loop's / the previous block's LDS reads are over
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int pr = wave + 4 * q;
-        if (pr >= NP) continue;
-        const int ct = pr / TAPS, tap = pr - ct * TAPS;
+        for (int q = 0; q < PPW; ++q) {
+            const int pr = wave + 4 * q;
+            if (pr >= NP || pr / TAPS != ct) continue;
+            const int tap = pr - ct * TAPS;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            atomicAdd(dW + ((int64_t)co * cin_total + (ci0 + chunk) * 32 + j) * TAPS + tap, acc[q][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                smem[(co * 32 + j) * TAPS + tap] = acc[q][r];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NTF; idx += 256) {
+            const int co = idx / (32 * TAPS), rest = idx - co * (32 * TAPS);
+            atomicAdd(dW + ((int64_t)(ct * 32 + co) * cin_total + (ci0 + chunk) * 32) * TAPS + rest, smem[idx]);
         }
     }
 }
@@ -259,7 +303,12 @@ int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int 
                   "wgrad: cin=%d cout=%d (cin a multiple of 32, cout 32, 64 or 96)", cin, cout);
     IFL_CHECK_ARG(taps == 9 || taps == 1, IFL_EINVAL, "wgrad: taps=%d", taps);
     int nwork = g.ntiles * B;
-    int gx = nwork < 48 ? nwork : 48;                             // tiles per workgroup bound the atomic traffic
+    // workgroups per input chunk: enough to give every CU two workgroups (each keeps its accumulators over its strided set of
+    // tiles and flushes them once with atomics, 9 KB per 32x32 tile, so more workgroups mean more atomic traffic)
+    const int chunks = cin / 32;
+    int gx = (512 + chunks - 1) / chunks;
+    if (gx < 16) gx = 16;
+    if (gx > nwork) gx = nwork;
     dim3 grid(gx, cin / 32), block(256);
 #define IFL_WG(CT, T) hipLaunchKernelGGL((wgrad_kernel<CT, T>), grid, block, 0, st, X, xs, xoff, DY, dys, dyoff, dW, cin_total, ci0, g, B)
     const int ct = cout / 32;

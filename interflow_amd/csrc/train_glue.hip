@@ -1,0 +1,229 @@
+// train_glue.hip -- the per-pixel operators of the coupling networks for the TRAINING path, forward and backward, as fused
+// bandwidth-bound kernels on channels-last tensors (the convolutions themselves are convg.hip's, forward / data gradient /
+// weight gradient).  They replace chains of ATen element-wise launches and their autograd graphs:
+//
+//   an_relu      y = relu((x + b) * exp(logs))                                flow.Conv2d's ActNorm (flow.py:60-64,
+//                                                                              FlowActNorms.py:87-92) followed by the ReLU of
+//                                                                              FlowAffineCouplingsAblation.py:250,252
+//   coupling     hs = h * exp(3 logs3); shift = hs[0::2], scale = sigmoid(hs[1::2] + 2) + eps      flow.py:80-82, Ablation.py:219-240
+//                branch 0 (reference "forward"):  z' = (z + shift) * scale,  logdet += sum log scale               :170-185
+//                branch 1 (reference "reverse"):  z' = z / scale - shift,    logdet -= sum log scale               :192-204
+//                applied to the channel range [c0, c0 + n) of z (the other channels are copied)
+//
+// Backward kernels recompute what they need from the forward inputs, write the input gradients, and reduce the parameter
+// gradients (per channel, over all pixels) and the per-sample log-det sums to per-block partial sums that the caller adds
+// (fixed order: bit-reproducible).
+#include "ifl_common.h"
+
+namespace {
+
+constexpr int GPX = 64;                       // pixels per block of the an_relu kernels (256 threads = 16 channel quads x 16 pixel lanes)
+
+__device__ __forceinline__ int64_t ring_px(int64_t p, int h, int w) {
+    const int x = p % w; const int64_t t = p / w; const int y = t % h; const int64_t b = t / h;
+    return (b * (h + 2) + y + 1) * (w + 2) + x + 1;
+}
+
+// x, y ringed [B][h+2][w+2][C], C = 64: thread = (pixel lane, channel quad)
+__global__ __launch_bounds__(256)
+void an_relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ bias,
+                        const float* __restrict__ logs, int64_t npx, int h, int w, int C)
+{
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const f32x4 b = *(const f32x4*)(bias + cq * 4);
+    f32x4 s = *(const f32x4*)(logs + cq * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = expf(s[e]);
+    for (int64_t p = (int64_t)blockIdx.x * GPX + pl; p < npx && p < (int64_t)(blockIdx.x + 1) * GPX; p += 16) {
+        const int64_t o = ring_px(p, h, w) * C + cq * 4;
+        f32x4 v = *(const f32x4*)(x + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float u = (v[e] + b[e]) * s[e]; v[e] = u > 0.f ? u : 0.f; }
+        *(f32x4*)(y + o) = v;
+    }
+}
+
+// dx = dy * [u > 0] * s;  part[block][0:C] = sum dx (= d bias),  part[block][C:2C] = sum dy [u > 0] u (= d logs)
+__global__ __launch_bounds__(256)
+void an_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                        const float* __restrict__ bias, const float* __restrict__ logs, float* __restrict__ part,
+                        int64_t npx, int h, int w, int C)
+{
+    __shared__ float red[16][2][64];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const f32x4 b = *(const f32x4*)(bias + cq * 4);
+    f32x4 s = *(const f32x4*)(logs + cq * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = expf(s[e]);
+    f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sl = sb;
+    for (int64_t p = (int64_t)blockIdx.x * GPX + pl; p < npx && p < (int64_t)(blockIdx.x + 1) * GPX; p += 16) {
+        const int64_t o = ring_px(p, h, w) * C + cq * 4;
+        const f32x4 v = *(const f32x4*)(x + o), g = *(const f32x4*)(dy + o);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = (v[e] + b[e]) * s[e];
+            const float du = u > 0.f ? g[e] : 0.f;
+            d[e] = du * s[e];
+            sb[e] += d[e];
+            sl[e] += du * u;
+        }
+        *(f32x4*)(dx + o) = d;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[pl][0][cq * 4 + e] = sb[e]; red[pl][1][cq * 4 + e] = sl[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][k][c];
+        part[(int64_t)blockIdx.x * 128 + k * 64 + c] = t;
+    }
+}
+
+__device__ __forceinline__ float sigmoid2(float p) { return 1.0f / (1.0f + expf(-(p + 2.0f))); }
+
+constexpr int CPX = 256;                      // pixels per block of the coupling kernels: thread = pixel, loop over channel pairs
+
+// z, zout [B][h][w][C] contiguous; hr ringed [B][h+2][w+2][hs] with rows (2 i, 2 i + 1) = (shift, scale) of channel c0 + i;
+// ldpart[b][blk] = this block's signed sum of log scale (blocks never straddle samples: grid (ceil(h w / CPX), B))
+__global__ __launch_bounds__(256)
+void coupling_fwd_kernel(const float* __restrict__ z, float* __restrict__ zout, const float* __restrict__ hr, int hs,
+                         const float* __restrict__ logs3, float eps, int branch, int c0, int n, float* __restrict__ ldpart,
+                         int h, int w, int C)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y, hw = h * w;
+    const int p = blockIdx.x * CPX + threadIdx.x;
+    float ld = 0.f;
+    if (p < hw) {
+        const int y = p / w, x = p - y * w;
+        const float* zp = z + ((int64_t)b * hw + p) * C;
+        float* zo = zout + ((int64_t)b * hw + p) * C;
+        const float* hp = hr + (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs;
+        for (int c = 0; c < C; ++c) {
+            float v = zp[c];
+            if (c >= c0 && c < c0 + n) {
+                const int i = c - c0;
+                const float sh = hp[2 * i] * expf(logs3[2 * i] * 3.0f);
+                const float sc = sigmoid2(hp[2 * i + 1] * expf(logs3[2 * i + 1] * 3.0f)) + eps;
+                if (branch == 0) { v = v + sh; v = v * sc; ld += logf(sc); }
+                else { v = v / sc; v = v - sh; ld -= logf(sc); }
+            }
+            zo[c] = v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ld += __shfl_xor(ld, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ld;
+    __syncthreads();
+    if (threadIdx.x == 0) ldpart[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dz (all channels), dh (interior pixels, rows [0, 2n) of the ringed gradient buffer, the rest must be zero already),
+// lpart[b * nblk + blk][2n] = per-block sums of d(hs) * hs * 3 (= d logs3)
+__global__ __launch_bounds__(256)
+void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzo, const float* __restrict__ dld,
+                         const float* __restrict__ hr, int hs, const float* __restrict__ logs3, float eps, int branch, int c0,
+                         int n, float* __restrict__ dz, float* __restrict__ dh, float* __restrict__ lpart, int h, int w, int C)
+{
+    extern __shared__ float sm[];             // [4 waves][2n]
+    const int b = blockIdx.y, hw = h * w;
+    const int p = blockIdx.x * CPX + threadIdx.x;
+    const float gl = dld ? dld[b] : 0.f;
+    const bool live = p < hw;
+    const int pc = live ? p : hw - 1;
+    const int y = pc / w, x = pc - y * w;
+    const float* zp = z + ((int64_t)b * hw + pc) * C;
+    const float* gp = dzo + ((int64_t)b * hw + pc) * C;
+    float* dzp = dz + ((int64_t)b * hw + pc) * C;
+    const int64_t ro = (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (live)
+        for (int c = 0; c < c0; ++c) dzp[c] = gp[c];
+    for (int i = 0; i < n; ++i) {
+        const int c = c0 + i;
+        const float e0 = expf(logs3[2 * i] * 3.0f), e1 = expf(logs3[2 * i + 1] * 3.0f);
+        const float hs0 = hr[ro + 2 * i] * e0, hs1 = hr[ro + 2 * i + 1] * e1;
+        const float sg = sigmoid2(hs1), sc = sg + eps;
+        const float g = gp[c], v = zp[c];
+        float dsh, dsc, dzi;
+        if (branch == 0) { dzi = g * sc; dsh = dzi; dsc = g * (v + hs0) + gl / sc; }
+        else { dzi = g / sc; dsh = -g; dsc = -g * v / (sc * sc) - gl / sc; }
+        const float dp = dsc * sg * (1.0f - sg);
+        float l0 = 0.f, l1 = 0.f;
+        if (live) {
+            dzp[c] = dzi;
+            dh[ro + 2 * i] = dsh * e0;
+            dh[ro + 2 * i + 1] = dp * e1;
+            l0 = dsh * hs0 * 3.0f;
+            l1 = dp * hs1 * 3.0f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64); }
+        if (lane == 0) { sm[wave * 2 * n + 2 * i] = l0; sm[wave * 2 * n + 2 * i + 1] = l1; }
+    }
+    if (live)
+        for (int c = c0 + n; c < C; ++c) dzp[c] = gp[c];
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * n; k += 256)
+        lpart[((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k] = (sm[k] + sm[2 * n + k]) + (sm[4 * n + k] + sm[6 * n + k]);
+}
+
+}  // namespace
+
+extern "C" int64_t ifl_an_relu_blocks(int B, int h, int w) { return ((int64_t)B * h * w + GPX - 1) / GPX; }
+
+extern "C" int ifl_an_relu_fwd(const float* x, float* y, const float* bias, const float* logs, int B, int h, int w, int C, void* stream)
+{
+    IFL_CHECK_ARG(x && y && bias && logs, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
+    const int64_t npx = (int64_t)B * h * w;
+    hipLaunchKernelGGL(an_relu_fwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, (hipStream_t)stream, x, y, bias, logs, npx, h, w, C);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_an_relu_bwd(const float* x, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
+                               int B, int h, int w, int C, void* stream)
+{
+    IFL_CHECK_ARG(x && dy && dx && bias && logs && partials, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
+    const int64_t npx = (int64_t)B * h * w;
+    hipLaunchKernelGGL(an_relu_bwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, bias, logs,
+                       partials, npx, h, w, C);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_coupling_blocks(int h, int w) { return (h * w + CPX - 1) / CPX; }
+
+extern "C" int ifl_coupling_fwd(const float* z, float* zout, const float* h_ring, int hstride, const float* logs3, float eps, int branch,
+                                int c0, int n, float* ldpart, int B, int h, int w, int C, void* stream)
+{
+    IFL_CHECK_ARG(z && zout && h_ring && logs3 && ldpart, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(c0 >= 0 && n >= 1 && c0 + n <= C && 2 * n <= hstride, IFL_EINVAL, "channel range [%d, %d) of %d, %d rows", c0, c0 + n, C, hstride);
+    IFL_CHECK_ARG(branch == 0 || branch == 1, IFL_EINVAL, "branch %d", branch);
+    hipLaunchKernelGGL(coupling_fwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 0, (hipStream_t)stream, z, zout, h_ring, hstride,
+                       logs3, eps, branch, c0, n, ldpart, h, w, C);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
+                                float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, int B, int h, int w,
+                                int C, void* stream)
+{
+    IFL_CHECK_ARG(z && dzout && h_ring && logs3 && dz && dh_ring && dlogs_part, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(c0 >= 0 && n >= 1 && c0 + n <= C && 2 * n <= hstride && n <= 64, IFL_EINVAL, "channel range [%d, %d) of %d, %d rows", c0, c0 + n, C, hstride);
+    IFL_CHECK_ARG(branch == 0 || branch == 1, IFL_EINVAL, "branch %d", branch);
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 8 * n * sizeof(float), (hipStream_t)stream, z, dzout, dld,
+                       h_ring, hstride, logs3, eps, branch, c0, n, dz, dh_ring, dlogs_part, h, w, C);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

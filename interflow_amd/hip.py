@@ -110,6 +110,20 @@ def lib():
     L.ifl_set_conv1_algo.restype = c_int
     L.ifl_set_conv3_algo.argtypes = [c_int]
     L.ifl_set_conv3_algo.restype = c_int
+    L.ifl_an_relu_blocks.argtypes = [c_int, c_int, c_int]
+    L.ifl_an_relu_blocks.restype = c_int64
+    L.ifl_an_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_an_relu_fwd.restype = c_int
+    L.ifl_an_relu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_an_relu_bwd.restype = c_int
+    L.ifl_coupling_blocks.argtypes = [c_int, c_int]
+    L.ifl_coupling_blocks.restype = c_int
+    L.ifl_coupling_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_coupling_fwd.restype = c_int
+    L.ifl_coupling_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.ifl_coupling_bwd.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -127,7 +141,8 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
-           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo")
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo",
+           "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 

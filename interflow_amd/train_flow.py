@@ -5,9 +5,10 @@ layer as a differentiable graph instead of by the fused inference kernels:
 
 * every convolution of the coupling networks -- 99.8 % of the FLOPs -- runs on the HIP implicit-GEMM kernels through
   `train_ops.conv2d_ring` (forward, data gradient and weight gradient all on the matrix cores);
-* the per-pixel glue (ActNorm, ReLU, sigmoid, the affine coupling, the C x C channel mix of the invertible 1x1 conv and the
-  log-det sums) are ATen ops on channels-last GPU tensors for now -- they are bandwidth-bound, a fraction of a percent of
-  the arithmetic, and are due to be replaced by fused backward kernels.
+* the per-pixel operators of the coupling networks -- ActNorm + ReLU, and exp(3 logs) / sigmoid / the affine coupling / its sum
+  of log scale -- are fused HIP kernels with hand-written backward kernels (`train_ops.an_relu_ring`, `coupling_apply`:
+  csrc/train_glue.hip); what is left to ATen is the flow-level ActNorm and the C x C channel mix of the invertible 1x1 conv
+  (a handful of launches per step), whose LU parameters go through torch autograd.
 
 The arithmetic follows the reference line by line (citations below); `tests/test_gpu_train.py` checks values and gradients
 against CPU autograd of the oracle.  Data-dependent ActNorm initialisation (FlowActNorms.py:29-43) happens here, on the first
@@ -91,28 +92,26 @@ def invconv(ic, x_cl, logdet=None, reverse=False):
 
 
 # ------------------------------------------------------------------------------------------------ coupling networks
+def _conv_actnorm_relu(conv, srcs, reals):
+    """flow.Conv2d (no bias) + its ActNorm + the following ReLU, ringed in and out.  Data-dependent initialisation of the
+    ActNorm (flow.py:57-63) from the convolution's interior on the first training pass."""
+    p = T.conv2d_ring(srcs, reals, conv.weight)
+    an = conv.actnorm
+    if not an.inited:
+        actnorm_init(an, p[:, 1:-1, 1:-1, :].detach())
+    assert p.shape[-1] == an.num_features, (tuple(p.shape), an.num_features)
+    return T.an_relu_ring(p, an.bias, an.logs)
+
+
 def coupling_nn(seq, srcs, reals):
     """FlowAffineCouplingsAblation.py:248-256: Conv2d 3x3 + ActNorm, ReLU, Conv2d 1x1 + ActNorm, ReLU, Conv2dZeros 3x3.
-    `srcs`: ringed channels-last inputs whose concatenation is the network's input; returns h [B,h,w,Cout] channels-last."""
+    `srcs`: ringed channels-last inputs whose concatenation is the network's input.  Returns the RAW output of the last
+    convolution (conv + bias, before the exp(3 logs) factor of flow.py:80-82, which the coupling kernel applies) as a ringed
+    tensor with pad32(Cout) channels."""
     c1, c2, c3 = seq[0], seq[2], seq[4]
-    p1 = T.conv2d_ring(srcs, reals, c1.weight)[:, 1:-1, 1:-1, :]                               # flow.py:25-64 (no bias)
-    a1, _ = actnorm(c1.actnorm, p1)
-    a1 = F.relu(a1)
-    p2 = T.conv2d_ring([T.ring_of(a1)], [a1.shape[-1]], c2.weight)[:, 1:-1, 1:-1, :]
-    a2, _ = actnorm(c2.actnorm, p2)
-    a2 = F.relu(a2)
-    cout = c3.weight.shape[0]
-    h = T.conv2d_ring([T.ring_of(a2)], [a2.shape[-1]], c3.weight, c3.bias)[:, 1:-1, 1:-1, :cout]
-    return h * torch.exp(c3.logs.reshape(-1) * c3.logscale_factor)                               # flow.py:80-82
-
-
-def _scale_shift(h, eps):
-    shift, scale = h[..., 0::2], h[..., 1::2]                                                    # thops.py:54-55 "cross"
-    return torch.sigmoid(scale + 2.) + eps, shift                                                # Ablation.py:229
-
-
-def _sum_log(scale):
-    return torch.log(scale).sum(dim=(1, 2, 3))                                                   # Ablation.py:216-217
+    a1 = _conv_actnorm_relu(c1, srcs, reals)                                                    # flow.py:25-64
+    a2 = _conv_actnorm_relu(c2, [a1], [a1.shape[-1]])
+    return T.conv2d_ring([a2], [a2.shape[-1]], c3.weight, c3.bias)
 
 
 def coupling(aff, z_cl, logdet, reverse, ft_ring):
@@ -123,29 +122,24 @@ def coupling(aff, z_cl, logdet, reverse, ft_ring):
     assert z_cl.shape[-1] == C, (z_cl.shape[-1], C)
     ch = aff.channels_for_nn
     eps = aff.affine_eps
+    assert aff.fAffine[4].logscale_factor == 3 and aff.fFeatures[4].logscale_factor == 3
 
-    def f_affine(z1):
-        z1r = T.ring_of(F.pad(z1, (0, T.pad32(ch) - ch)))
-        return _scale_shift(coupling_nn(aff.fAffine, [z1r, ft_ring], [ch, N_RRDB_CH]), eps)
+    def f_affine(z):
+        z1r = F.pad(z[..., :ch], (0, T.pad32(ch) - ch, 1, 1, 1, 1))
+        return coupling_nn(aff.fAffine, [z1r, ft_ring], [ch, N_RRDB_CH])
+
+    def f_features():
+        return coupling_nn(aff.fFeatures, [ft_ring], [N_RRDB_CH])
 
     if not reverse:                                                                              # :167-186
-        scale_ft, shift_ft = _scale_shift(coupling_nn(aff.fFeatures, [ft_ring], [N_RRDB_CH]), eps)
-        z = (z_cl + shift_ft) * scale_ft
-        logdet = logdet + _sum_log(scale_ft)
-        z1, z2 = z[..., :ch], z[..., ch:]
-        scale, shift = f_affine(z1)
-        z2 = (z2 + shift) * scale
-        logdet = logdet + _sum_log(scale)
-        return torch.cat([z1, z2], dim=-1), logdet
-    z1, z2 = z_cl[..., :ch], z_cl[..., ch:]                                                      # :187-207
-    scale, shift = f_affine(z1)
-    z2 = z2 / scale - shift
-    z = torch.cat([z1, z2], dim=-1)
-    logdet = logdet - _sum_log(scale)
-    scale_ft, shift_ft = _scale_shift(coupling_nn(aff.fFeatures, [ft_ring], [N_RRDB_CH]), eps)
-    z = z / scale_ft - shift_ft
-    logdet = logdet - _sum_log(scale_ft)
-    return z, logdet
+        z, ld = T.coupling_apply(z_cl, f_features(), aff.fFeatures[4].logs, eps, 0, 0, C)
+        logdet = logdet + ld
+        z, ld = T.coupling_apply(z, f_affine(z), aff.fAffine[4].logs, eps, 0, ch, C - ch)
+        return z, logdet + ld
+    z, ld = T.coupling_apply(z_cl, f_affine(z_cl), aff.fAffine[4].logs, eps, 1, ch, C - ch)      # :187-207
+    logdet = logdet + ld
+    z, ld = T.coupling_apply(z, f_features(), aff.fFeatures[4].logs, eps, 1, 0, C)
+    return z, logdet + ld
 
 
 # ------------------------------------------------------------------------------------------------ steps and the stack

@@ -59,6 +59,34 @@ def _padded_weight(weight: torch.Tensor, splits, cout_pad: int) -> torch.Tensor:
     return F.pad(torch.cat(parts, 1), (0, 0, 0, 0, 0, cout_pad - cout))
 
 
+def _packed(weight: torch.Tensor, splits, cout_pad: int, transposed: bool):
+    """Fragment-order copy of `weight` for ifl_conv2d, cached ON the parameter object per version (an optimizer step or a
+    load bumps `_version`; a cache keyed by address would outlive the tensor): forward weights, or -- `transposed` -- the
+    spatially flipped transpose [cin_pad, cout_pad, taps] whose source ranges are the data-gradient convolutions' weights."""
+    cache = getattr(weight, "_ifl_pack", None)
+    if cache is None or cache[0] != (weight._version, weight.data_ptr()):
+        cache = ((weight._version, weight.data_ptr()), {})
+        try:
+            weight._ifl_pack = cache
+        except AttributeError:                    # not attribute-capable (should not happen for Parameters): no caching
+            pass
+    key = (tuple(splits), cout_pad, transposed)
+    hit = cache[1].get(key)
+    if hit is not None:
+        return hit
+    wpad = _padded_weight(weight.detach().float(), splits, cout_pad)
+    if not transposed:
+        out = pack_weight(wpad)
+    else:
+        wt = wpad.flip(2).transpose(0, 1).contiguous()            # Wt[ci][co][tap] = W[co][ci][taps-1-tap]
+        out, o = [], 0
+        for _, padded in splits:
+            out.append(pack_weight(wt[o:o + padded].contiguous()))
+            o += padded
+    cache[1][key] = out
+    return out
+
+
 def _launch_conv(srcs, wpacked, bias, out, cout, taps, B, h, w):
     d = hip.IflConvDesc()
     d.nsrc = len(srcs)
@@ -90,10 +118,9 @@ class _ConvRing(torch.autograd.Function):
             assert s.shape[:3] == srcs[0].shape[:3] and s.shape[3] % 32 == 0, tuple(s.shape)
         splits = [(r, s.shape[3]) for r, s in zip(real_channels, srcs)]
         assert sum(r for r, _ in splits) == weight.shape[1], (splits, tuple(weight.shape))
-        wpad = _padded_weight(weight.detach().float(), splits, cout_pad)
         bpad = F.pad(bias.detach().float(), (0, cout_pad - cout)).contiguous() if bias is not None else None
         out = torch.zeros(B, hp, wp_, cout_pad, dtype=torch.float32, device=srcs[0].device)
-        _launch_conv(srcs, pack_weight(wpad), bpad, out, cout_pad, taps, B, h, w)
+        _launch_conv(srcs, _packed(weight, splits, cout_pad, False), bpad, out, cout_pad, taps, B, h, w)
         ctx.save_for_backward(weight, *srcs)
         ctx.meta = (splits, cout, cout_pad, taps, B, h, w, bias is not None)
         return out
@@ -130,18 +157,15 @@ class _ConvRing(torch.autograd.Function):
         need_src = [ctx.needs_input_grad[3 + i] for i in range(len(srcs))]
         if any(need_src):
             # data gradient = the same convolution with W^T, spatially flipped:  Wt[ci][co][tap] = W[co][ci][taps-1-tap]
-            wpad = _padded_weight(weight.detach().float(), splits, cout_pad)
-            wt = wpad.flip(2).transpose(0, 1).contiguous()            # [cin_pad, cout_pad, taps]
-            o = 0
+            wts = _packed(weight, splits, cout_pad, True)
             for i, s in enumerate(srcs):
                 padded = s.shape[3]
                 if need_src[i]:
-                    gi = torch.zeros_like(s)
-                    _launch_conv([g], pack_weight(wt[o:o + padded].contiguous()), None, gi, padded, taps, B, h, w)
+                    gi = torch.zeros(s.shape, dtype=torch.float32, device=s.device)
+                    _launch_conv([g], wts[i], None, gi, padded, taps, B, h, w)
                     grads.append(gi)
                 else:
                     grads.append(None)
-                o += padded
         else:
             grads += [None] * len(srcs)
         return tuple(grads)
@@ -153,3 +177,90 @@ def conv2d_ring(srcs, real_channels, weight, bias=None):
     channels, the rest zero) with `weight` [Cout, sum(real), k, k] (+ bias).  Returns a ringed tensor with pad32(Cout)
     channels (zero ring, zero padded channels)."""
     return _ConvRing.apply(weight, bias, tuple(real_channels), *srcs)
+
+
+# ------------------------------------------------------------------------------------------------ fused per-pixel operators
+class _AnRelu(torch.autograd.Function):
+    """y = relu((x + bias) * exp(logs)) on a ringed 64-channel tensor (ifl_an_relu_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, logs):
+        x = hip._dev_f32(x, "an_relu input")
+        B, hp, wp_, C = x.shape
+        b, l = bias.detach().reshape(-1).float().contiguous(), logs.detach().reshape(-1).float().contiguous()
+        y = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            hip.check(hip.lib().ifl_an_relu_fwd(hip._ptr(x), hip._ptr(y), hip._ptr(b), hip._ptr(l), B, hp - 2, wp_ - 2, C, hip._stream()),
+                      "ifl_an_relu_fwd")
+        ctx.save_for_backward(x, b, l)
+        ctx.shapes = (bias.shape, logs.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, b, l = ctx.saved_tensors
+        B, hp, wp_, C = x.shape
+        L = hip.lib()
+        gy = gy.contiguous()
+        dx = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
+        nblk = L.ifl_an_relu_blocks(B, hp - 2, wp_ - 2)
+        part = torch.empty(nblk, 2 * C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            hip.check(L.ifl_an_relu_bwd(hip._ptr(x), hip._ptr(gy), hip._ptr(dx), hip._ptr(b), hip._ptr(l), hip._ptr(part),
+                                        B, hp - 2, wp_ - 2, C, hip._stream()), "ifl_an_relu_bwd")
+        s = part.sum(dim=0)
+        return dx, s[:C].reshape(ctx.shapes[0]), s[C:].reshape(ctx.shapes[1])
+
+
+def an_relu_ring(x_ring, bias, logs):
+    """ReLU(ActNorm(x)) of flow.Conv2d + the following nn.ReLU, ringed 64-channel tensors in and out."""
+    return _AnRelu.apply(x_ring, bias, logs)
+
+
+class _Coupling(torch.autograd.Function):
+    """(z', sum of +-log scale per sample) of one affine coupling (ifl_coupling_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, z, h_ring, logs3, eps, branch, c0, n):
+        z = hip._dev_f32(z, "coupling z")
+        h_ring = hip._dev_f32(h_ring, "coupling h")
+        B, h, w, C = z.shape
+        assert h_ring.shape[:3] == (B, h + 2, w + 2), (tuple(z.shape), tuple(h_ring.shape))
+        l3 = logs3.detach().reshape(-1).float().contiguous()
+        assert l3.numel() == 2 * n
+        L = hip.lib()
+        nblk = L.ifl_coupling_blocks(h, w)
+        zo = torch.empty_like(z)
+        ldp = torch.empty(B, nblk, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            hip.check(L.ifl_coupling_fwd(hip._ptr(z), hip._ptr(zo), hip._ptr(h_ring), h_ring.shape[3], hip._ptr(l3), float(eps), branch,
+                                         c0, n, hip._ptr(ldp), B, h, w, C, hip._stream()), "ifl_coupling_fwd")
+        ctx.save_for_backward(z, h_ring, l3)
+        ctx.meta = (float(eps), branch, c0, n, logs3.shape)
+        return zo, ldp.sum(dim=1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, gld):
+        z, h_ring, l3 = ctx.saved_tensors
+        eps, branch, c0, n, lshape = ctx.meta
+        B, h, w, C = z.shape
+        L = hip.lib()
+        nblk = L.ifl_coupling_blocks(h, w)
+        gz = gz.contiguous()
+        gld = gld.contiguous().float() if gld is not None else None
+        dz = torch.empty_like(z)
+        dh = torch.zeros(h_ring.shape, dtype=torch.float32, device=z.device)
+        lp = torch.empty(B * nblk, 2 * n, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            hip.check(L.ifl_coupling_bwd(hip._ptr(z), hip._ptr(gz), hip._ptr(gld), hip._ptr(h_ring), h_ring.shape[3], hip._ptr(l3), eps,
+                                         branch, c0, n, hip._ptr(dz), hip._ptr(dh), hip._ptr(lp), B, h, w, C, hip._stream()),
+                      "ifl_coupling_bwd")
+        return dz, dh, lp.sum(dim=0).reshape(lshape), None, None, None, None
+
+
+def coupling_apply(z_cl, h_ring, logs3, eps, branch, c0, n):
+    """Affine coupling on channels [c0, c0+n) of the contiguous channels-last z with the raw Conv2dZeros output `h_ring`
+    (ringed); returns (z', per-sample signed sum of log scale)."""
+    return _Coupling.apply(z_cl.contiguous(), h_ring, logs3, eps, branch, c0, n)

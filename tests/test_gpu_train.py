@@ -175,7 +175,9 @@ def test_data_dependent_actnorm_init():
         z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
     finally:
         train_flow.actnorm = real
-    assert len(seen) == 36 + 32 * 4, len(seen)          # 36 flow-level ActNorms + 2 per coupling network
+    # the 36 flow-level ActNorms; the 128 inside the coupling networks' flow.Conv2d run in the fused an_relu kernel and are
+    # pinned, with these, to the reference's values by test_actnorm_init_against_reference_fixture
+    assert len(seen) == 36, len(seen)
     assert max(m for m, _ in seen) < 1e-4 and max(v for _, v in seen) < 1e-3, (max(m for m, _ in seen), max(v for _, v in seen))
     assert torch.isfinite(z).all() and torch.isfinite(ld).all()
     assert all(m.inited for m in model.modules() if type(m).__name__ == "ActNorm2d" and m in set(model.flow_upsampler.modules()))
