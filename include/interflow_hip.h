@@ -257,6 +257,14 @@ int     ifl_rrdb_encode(const float* params, int nb, const int* block_idxs, int 
                         float* fea_up1, float* fea_up2, float* fea_up4, float* fea_up0, float* out, float* blocks_out,
                         int B, int H, int W, void* stream);
 
+/* Separable gather-resize: the antialiased cubic down-scaling of the LR-consistency loss, train.py:102-103 =
+ * utils/resize_right.py:32-123 resize(x, 1/4, cubic, antialiasing=True).  x [N][Hin][Win] -> out [N][Hout][Wout], dimension -2
+ * first, then -1, as the reference; per output index a field of view of T taps: idx*[out][T] (int32 input indices, clamped for
+ * taps on the zero padding) and w*[out][T] (their normalised weights, 0 on the padding), built by the caller with the
+ * reference's formulas (interflow_amd/resize.py).  The adjoint (backward pass) is the same call with the transposed tables.   */
+int ifl_resize_sep(const float* x, float* out, int N, int Hin, int Win, int Hout, int Wout, const int* idxH, const float* wH,
+                   int TH, const int* idxW, const float* wW, int TW, void* stream);
+
 /* Image quantisation of the generation loop, generate_images.py:89-91:
  * out[b,h,w,c] = (uint8)(clip(x[b,c,h,w], 0, 1) * 255)   (NCHW float32 -> NHWC uint8, bit-exact with numpy).  C in {1,3,4}. */
 int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);

@@ -771,6 +771,17 @@ extern "C" int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, 
     return ifl_k_quantize_u8(x, out, B, C, (int64_t)H * W, (hipStream_t)stream);
 }
 
+extern "C" int ifl_resize_sep(const float* x, float* out, int N, int Hin, int Win, int Hout, int Wout, const int* idxH, const float* wH,
+                              int TH, const int* idxW, const float* wW, int TW, void* stream)
+{
+    IFL_CHECK_ARG((x && out) || (int64_t)N * Hout * Wout == 0, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(idxH && wH && idxW && wW, IFL_EINVAL, "null tap table");
+    IFL_CHECK_ARG(N >= 0 && N <= 65535 && Hin >= 1 && Win >= 1 && Hout >= 0 && Wout >= 0, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(TH >= 1 && TW >= 1 && TH <= 64 && TW <= 64, IFL_EINVAL, "taps %d, %d outside 1..64", TH, TW);
+    IFL_CHECK_ARG(Win <= 8192, IFL_ENOTSUP, "input rows of %d values exceed the LDS row buffer", Win);
+    return ifl_k_resize_sep(x, out, N, Hin, Win, Hout, Wout, idxH, wH, TH, idxW, wW, TW, (hipStream_t)stream);
+}
+
 extern "C" int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, float logdet_cov,
                                  float* scratch, float* out, int B, int C, int H, int W, void* stream)
 {

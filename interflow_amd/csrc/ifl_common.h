@@ -189,6 +189,8 @@ int ifl_k_squeeze_ring(const float* a, float* b, int B, int C, int H, int W, hip
 int ifl_k_unsqueeze_ring(const float* b, float* a, int B, int C, int H, int W, hipStream_t st);
 int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, int f, int reverse, hipStream_t st);
 int ifl_k_quantize_u8(const float* x, uint8_t* out, int B, int C, int64_t P, hipStream_t st);
+int ifl_k_resize_sep(const float* x, float* out, int N, int Hin, int Win, int Hout, int Wout, const int* idxH, const float* wH, int TH,
+                     const int* idxW, const float* wW, int TW, hipStream_t st);
 // pointwise.hip
 // in place on ringed NHWC; sf_next (decode only, may be NULL): also apply the next layer's z = (z + shiftFt) * scaleFt
 int ifl_k_anic(float* zr, const float* prm, int B, int C, int H, int W, int inverse, const float* sf_next, hipStream_t st);

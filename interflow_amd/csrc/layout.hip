@@ -262,3 +262,47 @@ int ifl_k_squeeze_nchw(const float* in, float* out, int B, int C, int H, int W, 
     IFL_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- separable gather-resize (ResizeRight's antialiased cubic of the LR-consistency loss, utils/resize_right.py:32-123) ---------
+// out[n][oy][ox] = sum_j wH[oy][j] * sum_i wW[ox][i] * x[n][idxH[oy][j]][idxW[ox][i]], dimension -2 first as the reference
+// (resize_right.py:97-116 walks the dims in order): per output index a field of view of T taps (left-aligned, 16 for x1/4) and
+// its normalised weights, built on the host with the reference's formulas; taps on the zero padding carry weight 0 and a
+// clamped index.  The same kernel evaluates the adjoint (the backward pass) from the transposed tables.  Block = one plane x
+// RS_ROWS output rows: the vertical pass writes RS_ROWS x Win values to LDS, the horizontal pass reads them.
+namespace {
+constexpr int RS_ROWS = 4;
+__global__ __launch_bounds__(256)
+void resize_sep_kernel(const float* __restrict__ x, float* __restrict__ out, int Hin, int Win, int Hout, int Wout,
+                       const int* __restrict__ idxH, const float* __restrict__ wH, int TH,
+                       const int* __restrict__ idxW, const float* __restrict__ wW, int TW)
+{
+    extern __shared__ float tmp[];            // [RS_ROWS][Win]
+    const int n = blockIdx.y, oy0 = blockIdx.x * RS_ROWS;
+    const float* xp = x + (int64_t)n * Hin * Win;
+    for (int k = threadIdx.x; k < RS_ROWS * Win; k += 256) {
+        const int r = k / Win, xx = k - r * Win, oy = oy0 + r;
+        float acc = 0.f;
+        if (oy < Hout)
+            for (int j = 0; j < TH; ++j) acc += wH[oy * TH + j] * xp[(int64_t)idxH[oy * TH + j] * Win + xx];
+        tmp[k] = acc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < RS_ROWS * Wout; k += 256) {
+        const int r = k / Wout, ox = k - r * Wout, oy = oy0 + r;
+        if (oy >= Hout) continue;
+        float acc = 0.f;
+        for (int i = 0; i < TW; ++i) acc += wW[ox * TW + i] * tmp[r * Win + idxW[ox * TW + i]];
+        out[((int64_t)n * Hout + oy) * Wout + ox] = acc;
+    }
+}
+}  // namespace
+
+int ifl_k_resize_sep(const float* x, float* out, int N, int Hin, int Win, int Hout, int Wout, const int* idxH, const float* wH, int TH,
+                     const int* idxW, const float* wW, int TW, hipStream_t st)
+{
+    if (N == 0 || Hout == 0 || Wout == 0) return 0;
+    dim3 grid((Hout + RS_ROWS - 1) / RS_ROWS, N), block(256);
+    hipLaunchKernelGGL(resize_sep_kernel, grid, block, RS_ROWS * Win * sizeof(float), st, x, out, Hin, Win, Hout, Wout, idxH, wH, TH, idxW, wW, TW);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

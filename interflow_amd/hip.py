@@ -124,6 +124,9 @@ def lib():
     L.ifl_coupling_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.ifl_coupling_bwd.restype = c_int
+    L.ifl_resize_sep.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_int, c_void_p]
+    L.ifl_resize_sep.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -142,7 +145,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo",
-           "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd")
+           "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)
 

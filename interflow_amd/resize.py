@@ -3,9 +3,11 @@
 (ResizeRight), for the arguments the training loop uses (last two dims, zero 'constant' padding, no by_convs).
 
 ResizeRight computes, per resized dimension, for every output position a 16-tap field of view and normalised weights
-(`resize_right.py:71-123`), then gathers and sums.  The same linear map is a dense matrix A [out, in] (taps that fall on
-the zero padding drop out), so the 2-D resize is `A_h @ X @ A_w^T`: two plain GEMMs per call (rocBLAS through
-torch.matmul), differentiable for free.  The weights follow the reference's formulas and float32 operation order.
+(`resize_right.py:71-123`), then gathers and sums.  Here the fields of view and weights are built once per size with the
+reference's formulas and float32 operation order (`resize_taps`); `ifl_resize_sep` (csrc/layout.hip) evaluates the two
+dimensions in the reference's order in one kernel, and the backward pass is the same kernel on the transposed tables
+(each input sample reaches at most 5 outputs at x1/4).  `resize_matrix` is the same map as a dense [out, in] matrix (tests,
+and the source of the transposed tables).  GPU tensors only: like the rest of the package there is no CPU evaluation.
 """
 from __future__ import annotations
 
@@ -47,17 +49,73 @@ def resize_matrix(in_sz: int, scale: float, device=None, support_sz: float = 4.0
     return A
 
 
+def _banded_tables(A: torch.Tensor):
+    """Dense [out, in] matrix with banded rows -> (idx [out, T] int32, w [out, T] float32): per row the columns from its first
+    to its last non-zero (T = the widest row), zero weights and clamped indices beyond a row's own band."""
+    out_sz, in_sz = A.shape
+    nz = A != 0
+    cols = torch.arange(in_sz)
+    first = torch.where(nz, cols, in_sz).min(dim=1).values.clamp(max=in_sz - 1)
+    last = torch.where(nz, cols, -1).max(dim=1).values.clamp(min=0)
+    T = int((last - first).max().item()) + 1
+    idx = first[:, None] + torch.arange(T)
+    w = torch.where(idx < in_sz, A.gather(1, idx.clamp(max=in_sz - 1)), torch.zeros(()))
+    return idx.clamp(max=in_sz - 1).to(torch.int32).contiguous(), w.to(torch.float32).contiguous()
+
+
+def resize_taps(in_sz: int, scale: float):
+    """Forward and adjoint tap tables of one dimension (CPU tensors): ((idx, w) for out <- in, (idx, w) for in <- out)."""
+    A = resize_matrix(in_sz, scale)
+    return _banded_tables(A), _banded_tables(A.t().contiguous())
+
+
 _cache = {}
 
 
-def resize_last2(x: torch.Tensor, scale: float = 0.25) -> torch.Tensor:
-    """resize(x, scale_factors=scale, interp_method=cubic, antialiasing=True) over the last two dims."""
-    H, W = x.shape[-2:]
-    key = (H, W, float(scale), str(x.device))
+def _tables(H, W, scale, device):
+    key = (H, W, float(scale), str(device))
     if key not in _cache:
         if len(_cache) > 16:
             _cache.clear()
-        _cache[key] = (resize_matrix(H, scale, x.device), resize_matrix(W, scale, x.device))
-    Ah, Aw = _cache[key]
-    # the reference resizes dim -2 first, then dim -1 (dims sorted by scale, stable)
-    return torch.matmul(torch.matmul(Ah, x), Aw.t())
+        fh, bh = resize_taps(H, scale)
+        fw, bw = resize_taps(W, scale)
+        _cache[key] = tuple(tuple(t.to(device) for t in pair) for pair in (fh, fw, bh, bw))
+    return _cache[key]
+
+
+def _launch(x3, Hout, Wout, th, tw):
+    from . import hip
+    N, Hin, Win = x3.shape
+    out = torch.empty(N, Hout, Wout, dtype=torch.float32, device=x3.device)
+    with torch.cuda.device(x3.device):
+        for n0 in range(0, N, 65535):
+            xs, os_ = x3[n0:n0 + 65535], out[n0:n0 + 65535]
+            hip.check(hip.lib().ifl_resize_sep(hip._ptr(xs), hip._ptr(os_), xs.shape[0], Hin, Win, Hout, Wout, hip._ptr(th[0]), hip._ptr(th[1]),
+                                               th[0].shape[1], hip._ptr(tw[0]), hip._ptr(tw[1]), tw[0].shape[1], hip._stream()),
+                      "ifl_resize_sep")
+    return out
+
+
+class _ResizeSep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        from . import hip
+        x = hip._dev_f32(x, "resize input")
+        H, W = x.shape[-2:]
+        fh, fw, bh, bw = _tables(H, W, scale, x.device)
+        ctx.meta = (x.shape, bh, bw)
+        out = _launch(x.reshape(-1, H, W), fh[0].shape[0], fw[0].shape[0], fh, fw)
+        return out.reshape(*x.shape[:-2], fh[0].shape[0], fw[0].shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, bh, bw = ctx.meta
+        g = g.contiguous().float()
+        dx = _launch(g.reshape(-1, g.shape[-2], g.shape[-1]), shape[-2], shape[-1], bh, bw)
+        return dx.reshape(shape), None
+
+
+def resize_last2(x: torch.Tensor, scale: float = 0.25) -> torch.Tensor:
+    """resize(x, scale_factors=scale, interp_method=cubic, antialiasing=True) over the last two dims (dimension -2 first,
+    then -1, as the reference), on the HIP kernel, differentiable."""
+    return _ResizeSep.apply(x, float(scale))
