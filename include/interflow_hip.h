@@ -120,12 +120,22 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
  * bit for bit, to ifl_flow_encode / ifl_flow_decode (same kernels, same order of operations).
  * ifl_flow_pass(decode = 0/1, flags = 0) is ifl_flow_encode / ifl_flow_decode.                                      */
 #define IFL_FLOW_COND_PREPARED 1
-/* IFL_FLOW_BF16_CONV1 (BASELINE.json configs[4]: "bf16 coupling-NN convs with fp32 ActNorm/logdet"): the conditioning part
- * of both coupling networks' first conv and fFeatures' 1x1 conv -- 93 % of the path's FLOPs -- run on the bf16 matrix
- * cores (operands rounded to bf16, fp32 accumulation); everything else stays fp32.  Pass it to ifl_cond_prepare and to
- * every ifl_flow_pass that does not use IFL_FLOW_COND_PREPARED.  Encode and decode still invert each other to fp32
- * accuracy; against the fp32 reference the outputs differ by the bf16 rounding (tolerance: tests/test_gpu_parity.py). */
+/* IFL_FLOW_BF16_CONV1 (BASELINE.json configs[4]: "bf16 coupling-NN convs with fp32 ActNorm/logdet"): the convolutions of the
+ * coupling networks that depend only on the conditioning features -- the conditioning part of both networks' first conv and
+ * fFeatures' 1x1 conv (direct form, v_mfma_f32_32x32x16_bf16) and fFeatures' last conv (Winograd F(2x2,3x3) with the
+ * transformed operands rounded, v_mfma_f32_16x16x16_bf16): 95 % of the path's FLOPs -- run on the bf16 matrix cores (operands
+ * rounded to bf16, fp32 accumulation).  They are the same function in both directions, so encode and decode still invert each
+ * other to fp32 accuracy.  ActNorm, ReLU, sigmoid, the couplings, the invertible 1x1 convs and the log-dets stay fp32.
+ * IFL_FLOW_BF16_CHAIN (only together with IFL_FLOW_BF16_CONV1) also runs fAffine's z-dependent convolutions (z1 taps, 1x1,
+ * last conv) with bf16 operands.  That is the whole of configs[4]'s arithmetic, at a price no implementation can avoid: the z1
+ * that the decode feeds to fAffine equals the encode's only to fp32 rounding, the bf16 rounding of it turns some of those
+ * last-bit differences into 2^-8 relative ones, and decode(encode(x)) then matches x to bf16 accuracy only (measured: 8e-3 on
+ * the benign fixture, 9e-2 in the wide-scale regime, against <= 1e-4 without this flag).
+ * Pass the flags to ifl_cond_prepare and to EVERY ifl_flow_pass of that conditioning (with or without
+ * IFL_FLOW_COND_PREPARED).  Against the fp32 reference the outputs differ by the bf16 rounding (tolerances:
+ * tests/test_gpu_parity.py).                                                                                              */
 #define IFL_FLOW_BF16_CONV1 2
+#define IFL_FLOW_BF16_CHAIN 4
 int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
                      float eps, int flags, void* stream);
 int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src, float* dst,

@@ -228,15 +228,15 @@ static int& conv3_algo()
 
 // fAffine's last conv + the coupling(s) of one step of the chain; advances `slots` by the log-det slots it wrote
 static int chain_conv3(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, const float* sf, int& slots,
-                       int mode, float eps, hipStream_t st)
+                       int mode, float eps, int bf16, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, 1);
     int rc;
-    if (conv3_algo() == 1) {
+    if (conv3_algo() == 1 || bf16) {          // the bf16 variant exists in the Winograd form only
         IflStepList one{};
         one.off[0] = L.param_off;
         rc = ifl_k_conv3w(mode == 0 ? 1 : 2, lv.ha, 0, IFL_HID, const_cast<float*>(sf), 0, lv.z, w.ldpart, w.ld_slots, slots, params, one, 1,
-                          off, w.B, lv.H, lv.W, L.C, eps, st);
+                          off, w.B, lv.H, lv.W, L.C, eps, bf16, st);
         slots += ifl_w3_slots(L.C, lv.H, lv.W, 0);
     } else {
         rc = ifl_k_conv3(sf, lv.ha, lv.z, w.ldpart, w.ld_slots, slots, params + L.param_off, off, lv.geom, w.B, L.C, mode, eps, st);
@@ -249,7 +249,7 @@ static int chain_conv3(const ifl_layer& L, const float* params, const IflWs& w, 
 // `slab` is the step's index among the level's conditional steps: its h2 slab holds the conditioning-only part of the first
 // conv (conv1_ft) and its sf slab fFeatures' shift / scale (conv3f); both are written by phase 1.
 static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
-                       int& slots, double& constant, float eps, hipStream_t st)
+                       int& slots, double& constant, float eps, int bf16, hipStream_t st)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
@@ -261,10 +261,10 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
     if (L.kind == 2) {
         const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
         const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
-        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, bf16, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_ENC, st);
-          rc = chain_conv3(L, params, w, lv, sf, slots, 0, eps, st); }
+          rc = chain_conv3(L, params, w, lv, sf, slots, 0, eps, bf16, st); }
         if (rc) return rc;
     }
     return 0;
@@ -273,7 +273,7 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
 // fapply_done: the previous kernel of the chain already applied this step's z = (z + shiftFt) * scaleFt; sf_next: apply the
 // next step's (the one the chain runs after this one) in this step's last kernel.
 static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
-                       int& slots, double& constant, float eps, hipStream_t st, bool fapply_done = false,
+                       int& slots, double& constant, float eps, int bf16, hipStream_t st, bool fapply_done = false,
                        const float* sf_next = nullptr)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
@@ -286,10 +286,10 @@ static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, 
             ProfScope ps(IFL_K_CONV3_DEC, st);
             if ((rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st))) return rc;
         }
-        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
+        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, bf16, st); }
         if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = chain_conv3(L, params, w, lv, sf, slots, 2, eps, st); }
+          rc = chain_conv3(L, params, w, lv, sf, slots, 2, eps, bf16, st); }
         if (rc) return rc;
     }
     { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, sf_next, st); }
@@ -411,16 +411,16 @@ int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params
           rc = ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st); }
     if (rc) return rc;
     ProfScope ps(IFL_K_CONV3_F, st);
-    if (conv3_algo() == 1)
+    if (conv3_algo() == 1 || bf16)
         return ifl_k_conv3w(0, h2 + IFL_HID, lv.h2_step, IFL_H2, lv.sf + (int64_t)s0 * lv.sf_step, lv.sf_step, nullptr, w.ldpart,
                             w.ld_slots, lv.ld_f0 + s0 * ifl_w3_slots(lv.C, lv.H, lv.W, 1), params, steps, nsteps, off, w.B, lv.H, lv.W,
-                            lv.C, eps, st);
+                            lv.C, eps, bf16, st);
     return ifl_k_conv3f(h2, lv.h2_step, lv.sf + (int64_t)s0 * lv.sf_step, lv.sf_step, w.ldpart, w.ld_slots,
                         lv.ld_f0 + s0 * lv.geom.ntiles, params, steps, nsteps, off, lv.geom, w.B, lv.C, eps, st);
 }
 
 // log-det slots per conditional step that fFeatures' kernel of the current algorithm writes
-int f_slots(const IflLevelWs& lv) { return conv3_algo() == 1 ? ifl_w3_slots(lv.C, lv.H, lv.W, 1) : lv.geom.ntiles; }
+int f_slots(const IflLevelWs& lv, int bf16) { return conv3_algo() == 1 || bf16 ? ifl_w3_slots(lv.C, lv.H, lv.W, 1) : lv.geom.ntiles; }
 
 int n_groups(int B)
 {
@@ -485,7 +485,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
 }
 
 int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float* params, const CondPlan& plan,
-                const IflWs& w, const float* src, float* dst, const float* logdet_in, float* logdet_out, float eps,
+                const IflWs& w, const float* src, float* dst, const float* logdet_in, float* logdet_out, float eps, int bf16,
                 hipStream_t st, hipEvent_t* ev)
 {
     const int B = w.B, H = w.H, W = w.W;
@@ -510,7 +510,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
             } else {
                 const int slab = plan.slab_of_layer[i];
                 if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
-                rc = step_encode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st);
+                rc = step_encode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, (bf16 >> 1) & 1, st);
             }
             if (rc) return rc;
         }
@@ -538,7 +538,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
                     if ((rc = wait_slab(lvl, nslab))) return rc;
                     sf_next = w.lv[lvl].sf + (int64_t)nslab * w.lv[lvl].sf_step;
                 }
-                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, st, fapply_done, sf_next);
+                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, (bf16 >> 1) & 1, st, fapply_done, sf_next);
                 fapply_done = sf_next != nullptr;
             }
             if (rc) return rc;
@@ -546,7 +546,7 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
     }
     // fFeatures' sums of log(scale) (phase 1): subtracted by the encode direction, added by the decode direction
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, decode ? 1.0 : -1.0,
-                             w.lv[0].ld_f0, plan.n[0] * f_slots(w.lv[0]), w.lv[1].ld_f0, plan.n[1] * f_slots(w.lv[1]), B, st);
+                             w.lv[0].ld_f0, plan.n[0] * f_slots(w.lv[0], bf16 & 1), w.lv[1].ld_f0, plan.n[1] * f_slots(w.lv[1], bf16 & 1), B, st);
 }
 
 int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int n_layers, const float* params, void* ws,
@@ -577,7 +577,7 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
     // phase 1 in the order the chain consumes the levels
     for (int k = 0; k < IFL_MAX_LEVELS && !prepared; ++k) {
         const int lvl = decode ? IFL_MAX_LEVELS - 1 - k : k;
-        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev, bf16, eps))) return rc;
+        if ((rc = launch_phase1(w, lvl, plan, params, decode, p1s, ev, bf16 & 1, eps))) return rc;
     }
     if (use_aux) IFL_HIP(hipEventRecord(f->aux_done, f->aux));
     else if (G > 1) IFL_HIP(hipEventRecord(f->fork, st));        // groups start after phase 1 on the caller's stream
@@ -588,7 +588,7 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
         IflWs wg = ws_slice(w, b0, b1 - b0);
         const float* li = logdet_in ? logdet_in + b0 : nullptr;
         if ((rc = chain_group(decode, layers, n_layers, params, plan, wg, src + b0 * n_src, dst + b0 * n_dst, li,
-                              logdet_out + b0, eps, sg, ev))) return rc;
+                              logdet_out + b0, eps, bf16, sg, ev))) return rc;
         if (g > 0) {
             IFL_HIP(hipEventRecord(f->join[g - 1], sg));
             IFL_HIP(hipStreamWaitEvent(st, f->join[g - 1], 0));
@@ -649,7 +649,7 @@ extern "C" int ifl_flow_decode(const ifl_layer* layers, int n_layers, const floa
 extern "C" int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
                                 float eps, int flags, void* stream)
 {
-    IFL_CHECK_ARG((flags & ~IFL_FLOW_BF16_CONV1) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
+    IFL_CHECK_ARG((flags & ~(IFL_FLOW_BF16_CONV1 | IFL_FLOW_BF16_CHAIN)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
     int rc = check_shape(B, H, W);
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
@@ -672,8 +672,10 @@ extern "C" int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float*
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && src && dst && logdet_out, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG((flags & ~(IFL_FLOW_COND_PREPARED | IFL_FLOW_BF16_CONV1)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
-    return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, (flags & IFL_FLOW_BF16_CONV1) != 0, layers, n_layers, params, ws, src, dst, logdet_in,
+    IFL_CHECK_ARG((flags & ~(IFL_FLOW_COND_PREPARED | IFL_FLOW_BF16_CONV1 | IFL_FLOW_BF16_CHAIN)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
+    IFL_CHECK_ARG(!(flags & IFL_FLOW_BF16_CHAIN) || (flags & IFL_FLOW_BF16_CONV1), IFL_EINVAL, "IFL_FLOW_BF16_CHAIN needs IFL_FLOW_BF16_CONV1");
+    // bf16 mask inside the drivers: bit 0 = the z-independent convolutions (bulk phase), bit 1 = fAffine's z-dependent ones (chain)
+    return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, ((flags & IFL_FLOW_BF16_CONV1) ? 1 : 0) | ((flags & IFL_FLOW_BF16_CHAIN) ? 2 : 0), layers, n_layers, params, ws, src, dst, logdet_in,
                     logdet_out, B, H, W, eps, (hipStream_t)stream);
 }
 
@@ -703,12 +705,12 @@ extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* 
         one.off[0] = layer->param_off;
         if ((rc = bulk_steps(w, lv, 0, params, one, 1, ifl_step_off(lv.C, 1), lvl + 1, 0, eps, st))) return rc;
     }
-    rc = reverse ? step_decode(*layer, params, w, lv, 0, slots, constant, eps, st)
-                 : step_encode(*layer, params, w, lv, 0, slots, constant, eps, st);
+    rc = reverse ? step_decode(*layer, params, w, lv, 0, slots, constant, eps, 0, st)
+                 : step_encode(*layer, params, w, lv, 0, slots, constant, eps, 0, st);
     if (rc) return rc;
     if ((rc = ifl_k_ring_to_nchw(lv.z, z_out, B, lv.C, lv.H, lv.W, st))) return rc;
     return ifl_k_ld_finalize(w.ldpart, slots, w.ld_slots, logdet_in, logdet_out, constant, reverse ? 1.0 : -1.0,
-                             lv.ld_f0, layer->kind == 2 ? f_slots(lv) : 0, 0, 0, B, st);
+                             lv.ld_f0, layer->kind == 2 ? f_slots(lv, 0) : 0, 0, 0, B, st);
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------------------------

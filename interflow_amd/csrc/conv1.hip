@@ -24,7 +24,9 @@
 //                        (ActNorm, ReLU, 1x1, ActNorm, ReLU -> h2[..][64:128]); fAffine's 64 raw pre-activation sums go
 //                        to h2[..][0:64].  ~98 % of the path's FLOPs, no dependence on the running z, so one launch per
 //                        level fills the chip without a partly filled last round per step.
-//   conv1_finish_kernel  per step, in the sequential chain: fAffine's remaining K = 9 x C/2 taps over z1 are added to
+//   conv1_finish_kernel  (BF16 = true: the same GEMMs with operands rounded to bf16 on v_mfma_f32_32x32x8_bf16, fp32 accumulate,
+//                        ActNorm / ReLU in fp32: BASELINE.json configs[4])
+//                        per step, in the sequential chain: fAffine's remaining K = 9 x C/2 taps over z1 are added to
 //                        the stored sums, then its ActNorm, ReLU, 1x1, ActNorm, ReLU -> ha (the slab keeps the raw sums,
 //                        so a prepared conditioning serves any number of passes: ifl_cond_prepare).
 
@@ -627,7 +629,7 @@ void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
 // ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
 // 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
 // of 8 with zero weights).
-template <int KZ>
+template <int KZ, bool BF16>
 __global__ __launch_bounds__(256, 2)
 void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__ h2P, float* __restrict__ haP,
                          const float* __restrict__ prm, IflStepOff off, IflGeom g, int C)
@@ -684,15 +686,22 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 xb[n] = *(const f32x4*)((const char*)lds + a0[n] + tapoff + kq * 32);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            if (BF16) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma32x4<true>(wa[m], xb[n], acc[m][n]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[m][n] = mfma32(wa[m][e], xb[n][e], acc[m][n]);
+            }
         }
     }
-    finish_and_store<NT, IFL_HID>(acc, prm + off.an1[0], prm + off.w2[0], prm + off.an2[0], haP, opix, lane, h);
+    finish_and_store<NT, IFL_HID, BF16>(acc, prm + off.an1[0], prm + off.w2[0], prm + off.an2[0], haP, opix, lane, h);
 }
 
 }  // namespace
@@ -735,11 +744,13 @@ extern "C" int ifl_dbg_read(void* host, size_t bytes) { return (int)hipMemcpyFro
 #endif
 
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
-                       const IflGeom& g, int B, int C, hipStream_t st)
+                       const IflGeom& g, int B, int C, int bf16, hipStream_t st)
 {
     dim3 grid(g.ntiles, B), block(256);
-    if (ifl_kz(C) == 8) hipLaunchKernelGGL(conv1_finish_kernel<8>, grid, block, 0, st, z, h2, ha, prm, off, g, C);
-    else if (ifl_kz(C) == 24) hipLaunchKernelGGL(conv1_finish_kernel<24>, grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    if (ifl_kz(C) == 8 && !bf16) hipLaunchKernelGGL((conv1_finish_kernel<8, false>), grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    else if (ifl_kz(C) == 24 && !bf16) hipLaunchKernelGGL((conv1_finish_kernel<24, false>), grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    else if (ifl_kz(C) == 8) hipLaunchKernelGGL((conv1_finish_kernel<8, true>), grid, block, 0, st, z, h2, ha, prm, off, g, C);
+    else if (ifl_kz(C) == 24) hipLaunchKernelGGL((conv1_finish_kernel<24, true>), grid, block, 0, st, z, h2, ha, prm, off, g, C);
     else { ifl_set_error("conv1_finish: C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();
     return 0;

@@ -55,7 +55,19 @@ __device__ __forceinline__ void bt4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
 
 // src: the 64 hidden channels (pixel stride `pstride` floats) of a ringed channels-last plane; step-dependent pointers are
 // resolved from blockIdx.z by the caller-provided tables (conv3f) or passed directly (chain).
-template <int MODE>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 to_bf16(f32x4 v) {
+    bf16x4w b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
+    return __builtin_bit_cast(s16x4, b);
+}
+
+// BF16: the products run on v_mfma_f32_16x16x16_bf16 -- a lane's four k-steps (channels 4q .. 4q+3 of the sub-chunk) are one
+// instruction -- with both operands (transformed weights U, transformed activations V) rounded to bf16, fp32 accumulate; the
+// transforms, bias / exp / sigmoid and the coupling stay fp32 (BASELINE.json configs[4]).
+template <int MODE, bool BF16>
 __global__ __launch_bounds__(256, 3)
 void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstride, float* sfAll, int64_t sf_step,
                    float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots, int slot0,
@@ -135,8 +147,11 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const f32x4 a = *(const f32x4*)&us[abase + p * 256];
+                if (BF16) acc[p] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16(a), to_bf16(v[p >> 2][p & 3]), acc[p], 0, 0, 0);
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[p] = mfma16w(a[e], v[p >> 2][p & 3][e], acc[p]);
+                    for (int e = 0; e < 4; ++e) acc[p] = mfma16w(a[e], v[p >> 2][p & 3][e], acc[p]);
+                }
             }
         }
     }
@@ -255,7 +270,7 @@ int ifl_w3_slots(int C, int H, int W, int f) { return (f ? ifl_nf(C) : ifl_na(C)
 // 2: decode chain (nsteps = 1, the step's parameter block in steps.off[0]; ifl_w3_slots(C, H, W, 0) slots from slot0)
 int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, float* sf, int64_t sf_step, float* z,
                  float* ldpart, int ld_slots, int slot0, const float* params, const IflStepList& steps,
-                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, hipStream_t st)
+                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, int bf16, hipStream_t st)
 {
     if (nsteps <= 0) return 0;
     if (C != 12 && C != 48) { ifl_set_error("conv3 (Winograd): C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
@@ -265,16 +280,13 @@ int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, floa
     if ((int64_t)(H + 2) * (W + 2) * pstride >= (int64_t)1 << 31) { ifl_set_error("conv3 (Winograd): plane too large for 32-bit offsets"); return IFL_ENOTSUP; }
     dim3 grid(nwg, B, nsteps * NT), block(256);
     const int64_t w3w = off.w3w[mode == W3_F ? 1 : 0], b3 = off.b3[mode == W3_F ? 1 : 0];
-    if (mode == W3_F)
-        hipLaunchKernelGGL((conv3w_kernel<W3_F>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
-                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
-    else if (mode == W3_ENC)
-        hipLaunchKernelGGL((conv3w_kernel<W3_ENC>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
-                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
-    else if (mode == W3_DEC)
-        hipLaunchKernelGGL((conv3w_kernel<W3_DEC>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, ld_slots, slot0,
-                           params, steps, w3w, b3, NT, NA, H, W, C, eps);
+#define IFL_W3_LAUNCH(M, BF) hipLaunchKernelGGL((conv3w_kernel<M, BF>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, \
+                                                ld_slots, slot0, params, steps, w3w, b3, NT, NA, H, W, C, eps)
+    if (mode == W3_F) { if (bf16) IFL_W3_LAUNCH(W3_F, true); else IFL_W3_LAUNCH(W3_F, false); }
+    else if (mode == W3_ENC) { if (bf16) IFL_W3_LAUNCH(W3_ENC, true); else IFL_W3_LAUNCH(W3_ENC, false); }
+    else if (mode == W3_DEC) { if (bf16) IFL_W3_LAUNCH(W3_DEC, true); else IFL_W3_LAUNCH(W3_DEC, false); }
     else { ifl_set_error("conv3 (Winograd): mode %d", mode); return IFL_EINVAL; }
+#undef IFL_W3_LAUNCH
     IFL_LAUNCH_CHECK();
     return 0;
 }

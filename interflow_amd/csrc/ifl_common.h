@@ -213,7 +213,7 @@ int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipS
 int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                          int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
-                       const IflGeom& g, int B, int C, hipStream_t st);
+                       const IflGeom& g, int B, int C, int bf16, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (fAffine's conv, both couplings), 2 = decode (fAffine's conv and coupling)
 int ifl_k_conv3(const float* sf, const float* ha, float* z, float* ldpart, int ld_slots, int slot0, const float* prm,
                 const IflStepOff& off, const IflGeom& g, int B, int C, int mode, float eps, hipStream_t st);
@@ -226,4 +226,4 @@ int ifl_w3_wgs(int H, int W);
 int ifl_w3_slots(int C, int H, int W, int f);
 int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, float* sf, int64_t sf_step, float* z,
                  float* ldpart, int ld_slots, int slot0, const float* params, const IflStepList& steps,
-                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, hipStream_t st);
+                 int nsteps, const IflStepOff& off, int B, int H, int W, int C, float eps, int bf16, hipStream_t st);

@@ -363,14 +363,16 @@ class FlowUpsamplerNet(nn.Module):
         self.scaleH, self.scaleW = 160 / H, 160 / W
         self._packed = None
         self.affine_eps = opt_get(opt, ['network_G', 'flow', 'CondAffineSeparatedAndCond', 'eps'], 0.0001)
-        # "fp32" (reference arithmetic) or "bf16": the conditioning part of the coupling networks' first conv and
-        # fFeatures' 1x1 conv on the bf16 matrix cores, fp32 everywhere else (BASELINE.json configs[4]); not a state-dict item
+        # "fp32" (reference arithmetic); "bf16": the coupling networks' convolutions that depend only on the conditioning (95 % of
+        # the FLOPs) on the bf16 matrix cores, operands rounded to bf16, fp32 accumulate -- encode and decode still invert each
+        # other to fp32 accuracy; "bf16_all": fAffine's z-dependent convolutions too (all of BASELINE.json configs[4]; the round
+        # trip then holds to bf16 accuracy only, see IFL_FLOW_BF16_CHAIN in interflow_hip.h).  Not a state-dict item.
         self.conv_dtype = "fp32"
 
     def _flags(self):
-        if self.conv_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"conv_dtype {self.conv_dtype!r}: expected 'fp32' or 'bf16'")
-        return hip.FLOW_BF16_CONV1 if self.conv_dtype == "bf16" else 0
+        if self.conv_dtype not in ("fp32", "bf16", "bf16_all"):
+            raise ValueError(f"conv_dtype {self.conv_dtype!r}: expected 'fp32', 'bf16' or 'bf16_all'")
+        return {"fp32": 0, "bf16": hip.FLOW_BF16_CONV1, "bf16_all": hip.FLOW_BF16_CONV1 | hip.FLOW_BF16_CHAIN}[self.conv_dtype]
 
     # ---- packed parameters, rebuilt when any parameter changes ----
     def _pack(self, device):
@@ -496,7 +498,7 @@ class FlowUpsamplerNet(nn.Module):
                 self._load_cond(ws, feats, B, H, W)
             hip.check(L.ifl_flow_pass(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
                                       hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps),
-                                      1 if decode else 0, hip.FLOW_COND_PREPARED if prepared else self._flags(), hip._stream()),
+                                      1 if decode else 0, (hip.FLOW_COND_PREPARED if prepared else 0) | self._flags(), hip._stream()),
                       "ifl_flow_pass")
         return out, ld_out
 

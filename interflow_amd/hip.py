@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("IFL_LIB_PATH") or os.path.join(_HERE, "libinterflow_h
 IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
 FLOW_COND_PREPARED = 1
 FLOW_BF16_CONV1 = 2
+FLOW_BF16_CHAIN = 4
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,

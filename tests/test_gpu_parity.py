@@ -671,6 +671,34 @@ def test_bf16_conv1_against_reference_and_round_trip(golden_dir, sd_np, model):
         fu.conv_dtype = "fp32"
 
 
+def test_bf16_all_convs_configs4_arithmetic(golden_dir, sd_np, model):
+    """conv_dtype='bf16_all' (IFL_FLOW_BF16_CHAIN): every coupling-network convolution with bf16 operands, the whole of
+    BASELINE.json configs[4]'s arithmetic.  Against the fp32 reference z stays inside BF16_TOL_Z; decode(encode(x)) holds to bf16
+    accuracy only (the bf16 rounding of the z-dependent operands differs between the directions wherever their fp32 values differ
+    in the last bit): tolerance 5e-2 of |x|max here, against 1e-4 for conv_dtype='bf16'."""
+    g = load(golden_dir, "full160_seed0.npz", sd_np)
+    B, H = 2, 160
+    x = t(synth.synth_images(1, B, H, H)).to(dev())
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(2, B, H, H).items()}
+    fu = model.flow_upsampler
+    fu.conv_dtype = "bf16"
+    try:
+        z1, _ = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        fu.conv_dtype = "bf16_all"
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        e1 = rel_close_maxnorm(z, g["z"], BF16_TOL_Z, what="bf16_all z vs reference")
+        rel_close_maxnorm(ld, g["ld"], BF16_TOL_LD, what="bf16_all logdet vs reference")
+        assert not torch.equal(z, z1), "the chain flag is not reaching the kernels"
+        xr, ldr = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False)
+        e3 = rel_close_maxnorm(xr, x, 5e-2, what="bf16_all decode(encode(x))")
+        prep = fu.prepare_cond(feats, B, H, H)
+        zp, ldp = model(x, None, lr_enc=prep, add_gt_noise=False, calc_loss=False)
+        assert torch.equal(zp, z) and torch.equal(ldp, ld)
+        print(f"bf16_all rel errs: z {e1:.2e} round trip {e3:.2e}")
+    finally:
+        fu.conv_dtype = "fp32"
+
+
 def test_bf16_512_patch(sd, model):
     """BASELINE.json configs[4] shape: one 512x512 patch; bf16 against the fp32 HIP path and its own inverse."""
     B, H = 1, 512
