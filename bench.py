@@ -48,7 +48,8 @@ def cpu_baseline(sd_np, seconds_budget=20.0):
     B = 4
     x = torch.from_numpy(synth.synth_images(1, B, PATCH, PATCH))
     feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(2, B, PATCH, PATCH).items()}
-    threads = torch.get_num_threads()
+    threads = min(16, os.cpu_count() or 1)         # the GPU box gives one GPU's job a 16-CPU share (nproc shows the whole machine)
+    torch.set_num_threads(threads)
 
     def one():
         z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B))
@@ -69,7 +70,7 @@ def cpu_baseline(sd_np, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,11 +96,12 @@ def main():
     model.eval().to(dev)
 
     B = args.batch
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.rand(B, 3, PATCH, PATCH, device=dev, generator=gen)
-    a = float(np.sqrt(3.0))
-    feats = {k: (torch.rand(B, 320, PATCH // d, PATCH // d, device=dev, generator=gen) * 2 - 1) * a
-             for k, d in (("fea_up4", 1), ("fea_up2", 2), ("fea_up1", 4))}
+    # the generators of the parity fixtures (interflow_amd/synth.py: U[0,1) images, zero-mean uniform features of rms 1), one seed
+    # per rank; 'fea_up4' is only looked up by the decode (FlowUpsamplerNet.py:279-280), never read: a placeholder stands for it
+    x = torch.from_numpy(synth.synth_images(1000 + rank, B, PATCH, PATCH)).to(dev)
+    feats = {k: torch.from_numpy(v).to(dev)
+             for k, v in synth.synth_features(2000 + rank, B, PATCH, PATCH, keys=("fea_up2", "fea_up1")).items()}
+    feats["fea_up4"] = torch.zeros(1, device=dev)
 
     def step():
         z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
@@ -263,8 +265,8 @@ def main():
         if bf16:
             fl = flops_total_direct / max(bf16["dom_n"], 1)           # the bf16 variant uses the direct form
             res["bf16_conv1"] = {"value": world * B * args.steps / bf16["elapsed"], "unit": "patches/s",
-                                 "ms_per_step": bf16["elapsed"] / args.steps * 1e3, "dtype": "bf16 operands / f32 accumulate in "
-                                 "conv1_ft, f32 elsewhere",
+                                 "ms_per_step": bf16["elapsed"] / args.steps * 1e3, "dtype": "bf16 operands / f32 accumulate in the "
+                                 "coupling networks' z-independent convolutions (conv1_ft, fFeatures' 1x1 and last conv), f32 elsewhere",
                                  "conv1_ft_bf16_kernel<1>": {"avg_launch_ms": bf16["dom_ms"] / max(bf16["dom_n"], 1),
                                                              "achieved_tflops": fl / (bf16["dom_ms"] / max(bf16["dom_n"], 1) * 1e-3) / 1e12,
                                                              "peak_tflops": 2500.0},

@@ -635,7 +635,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
                          const float* __restrict__ prm, IflStepOff off, IflGeom g, int C)
 {
     constexpr int NT = 1;
-    __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * 28];
+    __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * (KZ + 4)];     // KZ = 8: 14.6 KB, KZ = 24: 34 KB
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;
     const int b = blockIdx.y;
