@@ -249,6 +249,69 @@ int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const
                      float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, int B, int h, int w,
                      int C, void* stream);
 
+/* ---- gradient-enabled pass of one flow level (training: train.py:73,129 through FlowUpsamplerNet.encode) ----
+ * Replaces, for the encode direction, what torch autograd does over FlowStep.normal_flow (FlowStep.py:114-151) in the
+ * reference: ifl_train_level_fwd runs the level's steps and keeps the activations in the caller's buffers,
+ * ifl_train_level_bwd walks them in reverse.  All buffers are caller-owned device memory; the step array itself is host
+ * memory.  "ringed" = [B][h+2][w+2][channels] with a zero one-pixel ring that the kernels never write.
+ *
+ * ifl_pack_table: one launch over a device-resident table of re-layout jobs (dst[0..nelem) is written):
+ *   IFL_PACK_FWD         W [cout_real][real0+real1][taps] -> fragment order of ifl_conv2d with cout_pad outputs and pad0+pad1
+ *                        inputs (source 0: real0 of pad0 channels, source 1: real1 of pad1)
+ *   IFL_PACK_TRANSPOSED  the data-gradient weights Wt[a][co][tap] = W[co][a][taps-1-tap] for the padded input channels
+ *                        a0 + [0, acnt), fragment order with acnt outputs and cout_pad inputs
+ *   IFL_PACK_VECTOR      dst[i] = i < cout_real ? src[i] : 0, i < nelem (padded bias)
+ *   IFL_PACK_GRAD        dense gradient [cout_pad][pad0+pad1][taps] (ifl_conv2d_wgrad) -> the parameter's
+ *                        [cout_real][real0+real1][taps]                                                              */
+enum { IFL_PACK_FWD = 0, IFL_PACK_TRANSPOSED = 1, IFL_PACK_VECTOR = 2, IFL_PACK_GRAD = 3 };
+typedef struct ifl_pack_desc {
+    const float* src; float* dst; int64_t nelem;
+    int32_t mode, cout_real, cout_pad, taps, real0, pad0, real1, pad1, a0, acnt;
+} ifl_pack_desc;
+int ifl_pack_table(const ifl_pack_desc* table_dev, int n, int64_t max_elems, void* stream);
+
+/* One coupling network (fAffine or fFeatures, FlowAffineCouplingsAblation.py:248-256) of one step and its coupling. */
+typedef struct ifl_train_net {
+    const float *w1, *w2, *w3;                   /* packed forward weights: 3x3 (z1|ft -> 64), 1x1, Conv2dZeros 3x3 (64 -> hstride) */
+    const float *w1t, *w2t, *w3t;                /* packed data-gradient weights (w1t: towards z1 only, NULL without z1)       */
+    const float *an1_bias, *an1_logs, *an2_bias, *an2_logs;   /* the two flow.Conv2d ActNorms, 64 floats each (parameters)      */
+    const float *bias3, *logs3;                  /* Conv2dZeros bias padded to hstride floats; its logs [2n] (parameter)        */
+    float *p1, *a1, *p2, *a2;                    /* saved: conv outputs and ActNorm+ReLU outputs, ringed, 64 channels            */
+    float *hraw;                                 /* saved: raw Conv2dZeros output, ringed, hstride channels                      */
+    float *dW1, *dW2, *dW3;                      /* dense weight gradients [64][(32+)ft_ch][9], [64][64][1], [hstride][64][9]:
+                                                    accumulated with atomics, zero them before the backward                    */
+    float *an1_part, *an2_part;                  /* [ifl_an_relu_blocks][128] partial sums (d bias | d logs)                     */
+    float *dlogs_part, *dbias_part;              /* [B * ifl_coupling_blocks][2n] partial sums of d logs3 and of d bias3         */
+    float *ldpart;                               /* [B][ifl_coupling_blocks] signed per-block sums of log scale                  */
+    int32_t c0, n, hstride, has_z1;              /* coupling on channels [c0, c0+n); has_z1: the network also reads z[:, :ch]    */
+} ifl_train_net;
+
+/* One FlowStep: z_a = M z_in + c (ActNorm2d then InvertibleConv1x1, M = W diag(exp(logs)), c = M bias), then -- cond != 0 --
+ * coupling net[0] (z_a -> z_mid) and coupling net[1] (z_mid -> z_out), in the order the reference applies them.        */
+typedef struct ifl_train_step {
+    const float *M, *c;                          /* [C][C], [C]                                                                  */
+    float *dM_part;                              /* [ifl_affine_px_blocks(B h w)][C*C + C] partial sums of dM (row-major) | dc   */
+    float *z_in, *z_a, *z_mid, *z_out;           /* contiguous channels-last [B][h][w][C]; z_in is read, the others written      */
+    int32_t cond, pad_;
+    ifl_train_net net[2];
+} ifl_train_step;
+
+typedef struct ifl_train_level {
+    int32_t B, h, w, C, ch, nsteps, branch, ft_ch;   /* ch = C/2 channels feed the networks; branch as ifl_coupling_fwd         */
+    float eps;  int32_t pad_;
+    const float* ft;                             /* conditioning features, ringed, ft_ch channels (no gradient towards them)     */
+    float *z1ring, *dz1ring;                     /* scratch, ringed 32 channels, zero outside the interior's first ch channels   */
+    float *dz[4];                                /* scratch, [B][h][w][C]                                                        */
+    float *dh[2];                                /* scratch per network slot, ringed hstride channels, zero outside rows [0,2n)  */
+    float *d64[2];                               /* scratch, ringed 64 channels, zero ring                                       */
+    const ifl_train_step* steps;                 /* host array [nsteps]                                                          */
+} ifl_train_level;
+int64_t ifl_affine_px_blocks(int64_t npx);
+int ifl_train_level_fwd(const ifl_train_level* L, void* stream);
+/* dz_out: gradient wrt the last step's output; dld: gradient wrt the per-sample log-det [B] (or NULL); dz_in: gradient wrt
+ * the first step's input.  Weight gradients, partial sums and dM_part of every step are written as described above.    */
+int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out, const float* dld, float* dz_in, void* stream);
+
 /* ---- conditioning encoder ----
  * RRDBNet.forward(get_steps=True) (RRDBNet_arch.py:85-148) followed by RRDBGlowNet.rrdbPreprocessing
  * (RRDBGlowNet_arch.py:217-246) for the shipped options (scale 4, nf 64, gc 32, stackRRDB concat): x [B,3,H,W] ->

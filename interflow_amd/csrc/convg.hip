@@ -176,7 +176,7 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
 //   wave w     = the (co tile, tap) pairs p = w, w+4, ...: one 32x32 accumulator each, kept in registers over all the
 //                workgroup's tiles and added to dW with float atomics once at the end.
 template <int CT, int TAPS>        // CT = cout / 32 (1..3)
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)   // two workgroups per CU (74 KB of LDS each): without the bound CT = 2 takes 264 registers, one wave per SIMD
 void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __restrict__ DY, int dys, int dyoff,
                   float* __restrict__ dW, int cin_total, int ci0, IflGeom g, int B)
 {
@@ -275,6 +275,9 @@ void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __
     // fixed co the chunk's (ci, tap) are 32 * TAPS contiguous floats of dW, so each 32-row block of the accumulators goes through
     // LDS as T[co][ci][tap] and is added with coalesced float atomics (a lane-per-ci flush scatters every wave instruction over
     // 64 cache lines, which is an order of magnitude slower at the memory side).
+#ifdef IFL_EXP_NOFLUSH
+    if (acc[0][0] != 12345.678f) return;
+#endif
     for (int ct = 0; ct < CT; ++ct) {
         __syncthreads();                                          // the main loop's / the previous block's LDS reads are over
 #pragma unroll
@@ -303,10 +306,14 @@ int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int 
                   "wgrad: cin=%d cout=%d (cin a multiple of 32, cout 32, 64 or 96)", cin, cout);
     IFL_CHECK_ARG(taps == 9 || taps == 1, IFL_EINVAL, "wgrad: taps=%d", taps);
     int nwork = g.ntiles * B;
-    // workgroups per input chunk: enough to give every CU two workgroups (each keeps its accumulators over its strided set of
-    // tiles and flushes them once with atomics, 9 KB per 32x32 tile, so more workgroups mean more atomic traffic)
+    // workgroups per input chunk: two per CU in ONE round (512 slots; a few workgroups more would run as a second round
+    // beside an idle chip).  Each keeps its accumulators over its strided set of tiles and flushes them once with atomics,
+    // 9 KB per 32x32 tile, so more workgroups also mean more atomic traffic.
     const int chunks = cin / 32;
-    int gx = (512 + chunks - 1) / chunks;
+    int gx = 512 / chunks;
+#ifdef IFL_EXP_GX
+    if (getenv("IFL_EXP_GX")) gx = atoi(getenv("IFL_EXP_GX"));
+#endif
     if (gx < 16) gx = 16;
     if (gx > nwork) gx = nwork;
     dim3 grid(gx, cin / 32), block(256);

@@ -1,0 +1,331 @@
+// train_fused.hip -- the gradient-enabled pass of one flow level (encode direction) as two library calls:
+// ifl_train_level_fwd runs the level's FlowSteps (FlowStep.py:114-151) and keeps what the backward needs in caller-owned
+// buffers; ifl_train_level_bwd walks the steps in reverse and writes the input gradient, dense weight gradients and
+// per-block partial sums of the per-channel parameter gradients.  Between the two calls there is no host work per layer:
+// the Python side (interflow_amd/train_fused.py) only builds the descriptors once per shape, adds the partial sums and
+// routes the gradients to the parameters.
+//
+// Per conditional step (FlowAffineCouplingsAblation.py:159-256), for each of its two couplings in the order the reference
+// applies them:  [z1 -> ring]  conv 3x3 (z1 | ft -> 64)  ActNorm+ReLU  conv 1x1  ActNorm+ReLU  Conv2dZeros 3x3  coupling.
+// The convolutions are convg.hip's kernels (forward, data gradient with transposed weights, weight gradient), the per-pixel
+// operators train_glue.hip's.  New here:
+//   affine_px   z' = M z + c per pixel: ActNorm2d followed by InvertibleConv1x1 (FlowActNorms.py:87-92,
+//               Permutations.py:114-118) with M = W diag(exp(logs)), c = M bias (composed by the caller, who also owns the
+//               chain rule back to bias / logs / the LU factors); backward: dz = M^T dz', per-block sums of dz' (x) z and dz'
+//   ring_pack / ring_unpack_add   channels [0, ch) of a contiguous z <-> a ringed 32-channel plane (the coupling network's
+//               z1 input and its gradient)
+//   pack table  one launch that re-packs every convolution weight of a level from the parameters' own layout
+//               [Cout][Cin][k][k] into the kernels' fragment order (forward and transposed/flipped for the data gradients),
+//               pads the Conv2dZeros biases, and -- after the backward -- un-pads the dense weight gradients into the
+//               parameters' layout
+#include "ifl_common.h"
+#include "../../include/interflow_hip.h"
+
+int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
+                       float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, float* dbias_part, int B,
+                       int h, int w, int C, hipStream_t stream);
+
+namespace {
+
+constexpr int APX = 128;                      // pixels per block of the affine_px kernels
+
+template <int C>
+__global__ __launch_bounds__(256)
+void affine_px_fwd_kernel(const float* __restrict__ z, float* __restrict__ zo, const float* __restrict__ M,
+                          const float* __restrict__ c, int64_t npx)
+{
+    __shared__ float sM[C * C + C];
+    for (int i = threadIdx.x; i < C * C + C; i += 256) sM[i] = i < C * C ? M[i] : c[i - C * C];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    float v[C];
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        const f32x4 t = *(const f32x4*)(z + p * C + q * 4);
+        v[q * 4] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+    }
+    for (int q = 0; q < C / 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = q * 4 + e;
+            float a = sM[C * C + i];
+#pragma unroll
+            for (int j = 0; j < C; ++j) a = __builtin_fmaf(sM[i * C + j], v[j], a);
+            o[e] = a;
+        }
+        *(f32x4*)(zo + p * C + q * 4) = o;
+    }
+}
+
+// dz = M^T dzo;  part[block][i * C + j] = sum_p dzo[p][i] z[p][j],  part[block][C * C + i] = sum_p dzo[p][i]
+template <int C>
+__global__ __launch_bounds__(256)
+void affine_px_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzo, const float* __restrict__ M,
+                          float* __restrict__ dz, float* __restrict__ part, int64_t npx)
+{
+    constexpr int S = C + 1;                  // odd row stride: the per-pixel rows of consecutive threads start in distinct banks
+    __shared__ float sM[C * C];
+    __shared__ float sz[APX * S], sg[APX * S];
+    const int64_t p0 = (int64_t)blockIdx.x * APX;
+    for (int i = threadIdx.x; i < C * C; i += 256) sM[i] = M[i];
+    for (int i = threadIdx.x; i < APX * C; i += 256) {
+        const int p = i / C, k = i - p * C;
+        const bool in = p0 + p < npx;
+        sz[p * S + k] = in ? z[p0 * C + i] : 0.f;
+        sg[p * S + k] = in ? dzo[p0 * C + i] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < APX && p0 + threadIdx.x < npx) {
+        const float* g = sg + threadIdx.x * S;
+        float* o = dz + (p0 + threadIdx.x) * C;
+        for (int q = 0; q < C / 4; ++q) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < C; ++i) {
+                const float gi = g[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(sM[i * C + q * 4 + e], gi, a[e]);
+            }
+            *(f32x4*)(o + q * 4) = a;
+        }
+    }
+    float* out = part + (int64_t)blockIdx.x * (C * C + C);
+    for (int e = threadIdx.x; e < C * C + C; e += 256) {
+        float a = 0.f;
+        if (e < C * C) {
+            const int i = e / C, j = e - i * C;
+            for (int p = 0; p < APX; ++p) a = __builtin_fmaf(sg[p * S + i], sz[p * S + j], a);
+        } else {
+            const int i = e - C * C;
+            for (int p = 0; p < APX; ++p) a += sg[p * S + i];
+        }
+        out[e] = a;
+    }
+}
+
+__device__ __forceinline__ int64_t ring_index(int64_t p, int h, int w) {
+    const int x = p % w; const int64_t t = p / w; const int y = t % h; const int64_t b = t / h;
+    return (b * (h + 2) + y + 1) * (w + 2) + x + 1;
+}
+
+// ring[b][y+1][x+1][k] = z[b][y][x][k], k < ch (ring: [..][32], its other entries stay as they are: zero)
+__global__ __launch_bounds__(256)
+void ring_pack_kernel(const float* __restrict__ z, float* __restrict__ ring, int64_t npx, int h, int w, int C, int ch)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx * ch) return;
+    const int64_t p = i / ch; const int k = i - p * ch;
+    ring[ring_index(p, h, w) * 32 + k] = z[p * C + k];
+}
+
+// dz[b][y][x][k] += dring[b][y+1][x+1][k], k < ch
+__global__ __launch_bounds__(256)
+void ring_unpack_add_kernel(const float* __restrict__ dring, float* __restrict__ dz, int64_t npx, int h, int w, int C, int ch)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx * ch) return;
+    const int64_t p = i / ch; const int k = i - p * ch;
+    dz[p * C + k] += dring[ring_index(p, h, w) * 32 + k];
+}
+
+// padded input channel -> the parameter's input channel (or -1): source 0 holds real0 of pad0 channels, source 1 real1 of pad1
+__device__ __forceinline__ int real_channel(const ifl_pack_desc& d, int cip) {
+    if (cip < d.pad0) return cip < d.real0 ? cip : -1;
+    const int k = cip - d.pad0;
+    return k < d.real1 ? d.real0 + k : -1;
+}
+
+__global__ __launch_bounds__(256)
+void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
+{
+    const ifl_pack_desc d = table[blockIdx.y];
+    const int cin_real = d.real0 + d.real1, cin_pad = d.pad0 + d.pad1;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < d.nelem; idx += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        if (d.mode == IFL_PACK_FWD || d.mode == IFL_PACK_TRANSPOSED) {
+            // fragment order [group of 32 outputs][chunk of 32 inputs][tap][kq][half][i][e]
+            const int e = idx & 3, i = (idx >> 2) & 31, hh = (idx >> 7) & 1, kq = (idx >> 8) & 3;
+            int64_t r = idx >> 10;
+            const int tap = r % d.taps; r /= d.taps;
+            const int nch = (d.mode == IFL_PACK_FWD ? cin_pad : d.cout_pad) / 32;
+            const int chunk = r % nch, g = r / nch;
+            const int o = g * 32 + i, k = chunk * 32 + kq * 8 + hh * 4 + e;
+            if (d.mode == IFL_PACK_FWD) {
+                const int ci = real_channel(d, k);
+                if (o < d.cout_real && ci >= 0) v = d.src[((int64_t)o * cin_real + ci) * d.taps + tap];
+            } else {                          // Wt[a][co][tap] = W[co][a][taps - 1 - tap] for the padded input channels a0 + [0, acnt)
+                const int ci = real_channel(d, d.a0 + o);
+                if (k < d.cout_real && ci >= 0) v = d.src[((int64_t)k * cin_real + ci) * d.taps + (d.taps - 1 - tap)];
+            }
+        } else if (d.mode == IFL_PACK_VECTOR) {
+            if (idx < d.cout_real) v = d.src[idx];
+        } else {                              // IFL_PACK_GRAD: dense [cout_pad][cin_pad][taps] -> the parameter's [cout][cin][taps]
+            const int tap = idx % d.taps; int64_t r = idx / d.taps;
+            const int ci = r % cin_real, co = r / cin_real;
+            const int col = ci < d.real0 ? ci : d.pad0 + (ci - d.real0);
+            v = d.src[((int64_t)co * cin_pad + col) * d.taps + tap];
+        }
+        d.dst[idx] = v;
+    }
+}
+
+template <int C>
+int launch_affine_fwd(const float* z, float* zo, const float* M, const float* c, int64_t npx, hipStream_t st) {
+    hipLaunchKernelGGL(affine_px_fwd_kernel<C>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, z, zo, M, c, npx);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+template <int C>
+int launch_affine_bwd(const float* z, const float* dzo, const float* M, float* dz, float* part, int64_t npx, hipStream_t st) {
+    hipLaunchKernelGGL(affine_px_bwd_kernel<C>, dim3((unsigned)((npx + APX - 1) / APX)), dim3(256), 0, st, z, dzo, M, dz, part, npx);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+int affine_fwd(const float* z, float* zo, const float* M, const float* c, int64_t npx, int C, hipStream_t st) {
+    if (C == 12) return launch_affine_fwd<12>(z, zo, M, c, npx, st);
+    if (C == 48) return launch_affine_fwd<48>(z, zo, M, c, npx, st);
+    ifl_set_error("affine_px: C=%d (12 or 48)", C);
+    return IFL_ENOTSUP;
+}
+int affine_bwd(const float* z, const float* dzo, const float* M, float* dz, float* part, int64_t npx, int C, hipStream_t st) {
+    if (C == 12) return launch_affine_bwd<12>(z, dzo, M, dz, part, npx, st);
+    if (C == 48) return launch_affine_bwd<48>(z, dzo, M, dz, part, npx, st);
+    ifl_set_error("affine_px: C=%d (12 or 48)", C);
+    return IFL_ENOTSUP;
+}
+
+int conv(const float* s0, int c0, const float* s1, int c1, const float* w, const float* bias, float* out, int cout, int taps,
+         int B, int h, int w_, hipStream_t st)
+{
+    ifl_conv_desc d = {};
+    d.src[0] = s0; d.src_stride[0] = c0; d.src_ch[0] = c0;
+    d.nsrc = 1;
+    if (s1) { d.src[1] = s1; d.src_stride[1] = c1; d.src_ch[1] = c1; d.nsrc = 2; }
+    d.w = w; d.bias = bias; d.out = out; d.out_stride = cout; d.cout = cout; d.taps = taps;
+    d.alpha = d.beta = 1.f;
+    return ifl_conv2d(&d, B, h, w_, st);
+}
+
+#define IFL_TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+int check_level(const ifl_train_level* L) {
+    IFL_CHECK_ARG(L && L->steps && L->nsteps >= 1, IFL_EINVAL, "train level: no steps");
+    IFL_CHECK_ARG(L->B >= 1 && L->h >= 1 && L->w >= 1 && (L->C == 12 || L->C == 48), IFL_ENOTSUP,
+                  "train level: B=%d h=%d w=%d C=%d (C 12 or 48)", L->B, L->h, L->w, L->C);
+    IFL_CHECK_ARG(L->ch >= 1 && L->ch <= 32 && L->ch < L->C, IFL_ENOTSUP, "train level: %d of %d channels feed the coupling networks", L->ch, L->C);
+    IFL_CHECK_ARG(L->branch == 0 || L->branch == 1, IFL_EINVAL, "branch %d", L->branch);
+    for (int s = 0; s < L->nsteps; ++s) {
+        const ifl_train_step& S = L->steps[s];
+        IFL_CHECK_ARG(S.M && S.c && S.dM_part && S.z_in && S.z_a, IFL_EINVAL, "train step %d: null pointer", s);
+        if (!S.cond) continue;
+        IFL_CHECK_ARG(L->ft && L->ft_ch % 32 == 0 && L->z1ring && L->dz1ring && S.z_mid && S.z_out, IFL_EINVAL, "train step %d: null pointer", s);
+        for (int i = 0; i < 2; ++i) {
+            const ifl_train_net& N = S.net[i];
+            IFL_CHECK_ARG(N.w1 && N.w2 && N.w3 && N.w2t && N.w3t && N.p1 && N.a1 && N.p2 && N.a2 && N.hraw && N.dW1 && N.dW2 && N.dW3 &&
+                          N.an1_part && N.an2_part && N.dlogs_part && N.dbias_part && N.ldpart && N.bias3 && N.logs3 &&
+                          N.an1_bias && N.an1_logs && N.an2_bias && N.an2_logs && L->dh[i] && (!N.has_z1 || N.w1t),
+                          IFL_EINVAL, "train step %d net %d: null pointer", s, i);
+            IFL_CHECK_ARG(N.n >= 1 && N.c0 >= 0 && N.c0 + N.n <= L->C && N.hstride % 32 == 0 && 2 * N.n <= N.hstride && N.hstride <= 96,
+                          IFL_EINVAL, "train step %d net %d: channels [%d, %d) of %d, %d rows", s, i, N.c0, N.c0 + N.n, L->C, N.hstride);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ifl_pack_table(const ifl_pack_desc* table_dev, int n, int64_t max_elems, void* stream)
+{
+    IFL_CHECK_ARG(table_dev && n >= 1 && n <= 65535 && max_elems >= 1, IFL_EINVAL, "pack table: %d entries", n);
+    int64_t gx = (max_elems + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)gx, n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t ifl_affine_px_blocks(int64_t npx) { return (npx + APX - 1) / APX; }
+
+extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
+{
+    IFL_TRY(check_level(L));
+    hipStream_t st = (hipStream_t)stream;
+    const int B = L->B, h = L->h, w = L->w, C = L->C;
+    const int64_t npx = (int64_t)B * h * w;
+    for (int s = 0; s < L->nsteps; ++s) {
+        const ifl_train_step& S = L->steps[s];
+        IFL_TRY(affine_fwd(S.z_in, S.z_a, S.M, S.c, npx, C, st));
+        if (!S.cond) continue;
+        for (int i = 0; i < 2; ++i) {
+            const ifl_train_net& N = S.net[i];
+            const float* zsrc = i == 0 ? S.z_a : S.z_mid;
+            float* zdst = i == 0 ? S.z_mid : S.z_out;
+            if (N.has_z1) {
+                hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
+                IFL_LAUNCH_CHECK();
+                IFL_TRY(conv(L->z1ring, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+            } else {
+                IFL_TRY(conv(L->ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+            }
+            IFL_TRY(ifl_an_relu_fwd(N.p1, N.a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
+            IFL_TRY(conv(N.a1, 64, nullptr, 0, N.w2, nullptr, N.p2, 64, 1, B, h, w, st));
+            IFL_TRY(ifl_an_relu_fwd(N.p2, N.a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
+            IFL_TRY(conv(N.a2, 64, nullptr, 0, N.w3, N.bias3, N.hraw, N.hstride, 9, B, h, w, st));
+            IFL_TRY(ifl_coupling_fwd(zsrc, zdst, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart, B, h, w, C, st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out, const float* dld, float* dz_in, void* stream)
+{
+    IFL_TRY(check_level(L));
+    IFL_CHECK_ARG(dz_out && dz_in && L->dz[0] && L->dz[1] && L->dz[2] && L->dz[3] && L->d64[0] && L->d64[1], IFL_EINVAL, "train level backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = L->B, h = L->h, w = L->w, C = L->C;
+    const int64_t npx = (int64_t)B * h * w;
+    const float* g = dz_out;
+    for (int s = L->nsteps - 1; s >= 0; --s) {
+        const ifl_train_step& S = L->steps[s];
+        if (S.cond) {
+            for (int i = 1; i >= 0; --i) {
+                const ifl_train_net& N = S.net[i];
+                const float* zsrc = i == 0 ? S.z_a : S.z_mid;
+                float* dzn = L->dz[i];                  // gradient wrt this coupling's input
+                float* dh = L->dh[i];
+                float* da = L->d64[0];
+                float* dp = L->d64[1];
+                IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part,
+                                           N.dbias_part, B, h, w, C, st));
+                // Conv2dZeros 3x3: a2 -> hraw
+                IFL_TRY(ifl_conv2d_wgrad(N.a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
+                IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
+                IFL_TRY(ifl_an_relu_bwd(N.p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part, B, h, w, 64, st));
+                // 1x1: a1 -> p2
+                IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
+                IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
+                IFL_TRY(ifl_an_relu_bwd(N.p1, da, dp, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
+                // first 3x3: (z1 | ft) -> p1
+                if (N.has_z1) {
+                    const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
+                    hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
+                    IFL_LAUNCH_CHECK();
+                    IFL_TRY(ifl_conv2d_wgrad(L->z1ring, 32, 0, 32, dp, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
+                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
+                    IFL_TRY(conv(dp, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring, 32, 9, B, h, w, st));
+                    hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring, dzn, npx, h, w, C, L->ch);
+                    IFL_LAUNCH_CHECK();
+                } else {
+                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
+                }
+                g = dzn;
+            }
+        }
+        float* out = s == 0 ? dz_in : L->dz[2 + (s & 1)];
+        IFL_TRY(affine_bwd(S.z_in, g, S.M, out, S.dM_part, npx, C, st));
+        g = out;
+    }
+    return 0;
+}

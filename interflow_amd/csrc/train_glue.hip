@@ -122,13 +122,15 @@ void coupling_fwd_kernel(const float* __restrict__ z, float* __restrict__ zout, 
 }
 
 // dz (all channels), dh (interior pixels, rows [0, 2n) of the ringed gradient buffer, the rest must be zero already),
-// lpart[b * nblk + blk][2n] = per-block sums of d(hs) * hs * 3 (= d logs3)
+// lpart[b * nblk + blk][2n] = per-block sums of d(hs) * hs * 3 (= d logs3); bpart (optional), same shape = per-block sums of
+// d h (= the gradient of Conv2dZeros' bias)
 __global__ __launch_bounds__(256)
 void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzo, const float* __restrict__ dld,
                          const float* __restrict__ hr, int hs, const float* __restrict__ logs3, float eps, int branch, int c0,
-                         int n, float* __restrict__ dz, float* __restrict__ dh, float* __restrict__ lpart, int h, int w, int C)
+                         int n, float* __restrict__ dz, float* __restrict__ dh, float* __restrict__ lpart,
+                         float* __restrict__ bpart, int h, int w, int C)
 {
-    extern __shared__ float sm[];             // [4 waves][2n]
+    extern __shared__ float sm[];             // [4 waves][2n] sums for d logs3, then [4 waves][2n] for d bias
     const int b = blockIdx.y, hw = h * w;
     const int p = blockIdx.x * CPX + threadIdx.x;
     const float gl = dld ? dld[b] : 0.f;
@@ -152,23 +154,32 @@ void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ 
         if (branch == 0) { dzi = g * sc; dsh = dzi; dsc = g * (v + hs0) + gl / sc; }
         else { dzi = g / sc; dsh = -g; dsc = -g * v / (sc * sc) - gl / sc; }
         const float dp = dsc * sg * (1.0f - sg);
-        float l0 = 0.f, l1 = 0.f;
+        float l0 = 0.f, l1 = 0.f, b0 = 0.f, b1 = 0.f;
         if (live) {
             dzp[c] = dzi;
-            dh[ro + 2 * i] = dsh * e0;
-            dh[ro + 2 * i + 1] = dp * e1;
+            b0 = dsh * e0;
+            b1 = dp * e1;
+            dh[ro + 2 * i] = b0;
+            dh[ro + 2 * i + 1] = b1;
             l0 = dsh * hs0 * 3.0f;
             l1 = dp * hs1 * 3.0f;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64); }
         if (lane == 0) { sm[wave * 2 * n + 2 * i] = l0; sm[wave * 2 * n + 2 * i + 1] = l1; }
+        if (bpart) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64); }
+            if (lane == 0) { sm[(4 + wave) * 2 * n + 2 * i] = b0; sm[(4 + wave) * 2 * n + 2 * i + 1] = b1; }
+        }
     }
     if (live)
         for (int c = c0 + n; c < C; ++c) dzp[c] = gp[c];
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * n; k += 256)
+    for (int k = threadIdx.x; k < 2 * n; k += 256) {
         lpart[((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k] = (sm[k] + sm[2 * n + k]) + (sm[4 * n + k] + sm[6 * n + k]);
+        if (bpart) bpart[((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k] = (sm[8 * n + k] + sm[10 * n + k]) + (sm[12 * n + k] + sm[14 * n + k]);
+    }
 }
 
 }  // namespace
@@ -214,16 +225,24 @@ extern "C" int ifl_coupling_fwd(const float* z, float* zout, const float* h_ring
     return 0;
 }
 
-extern "C" int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
-                                float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, int B, int h, int w,
-                                int C, void* stream)
+int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
+                       float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, float* dbias_part, int B,
+                       int h, int w, int C, hipStream_t stream)
 {
     IFL_CHECK_ARG(z && dzout && h_ring && logs3 && dz && dh_ring && dlogs_part, IFL_EINVAL, "null pointer");
     IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1, IFL_EINVAL, "bad shape");
     IFL_CHECK_ARG(c0 >= 0 && n >= 1 && c0 + n <= C && 2 * n <= hstride && n <= 64, IFL_EINVAL, "channel range [%d, %d) of %d, %d rows", c0, c0 + n, C, hstride);
     IFL_CHECK_ARG(branch == 0 || branch == 1, IFL_EINVAL, "branch %d", branch);
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 8 * n * sizeof(float), (hipStream_t)stream, z, dzout, dld,
-                       h_ring, hstride, logs3, eps, branch, c0, n, dz, dh_ring, dlogs_part, h, w, C);
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 16 * n * sizeof(float), stream, z, dzout, dld,
+                       h_ring, hstride, logs3, eps, branch, c0, n, dz, dh_ring, dlogs_part, dbias_part, h, w, C);
     IFL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
+                                float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, int B, int h, int w,
+                                int C, void* stream)
+{
+    return ifl_k_coupling_bwd(z, dzout, dld, h_ring, hstride, logs3, eps, branch, c0, n, dz, dh_ring, dlogs_part, nullptr, B, h, w, C,
+                              (hipStream_t)stream);
 }

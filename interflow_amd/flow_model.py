@@ -359,6 +359,29 @@ class InterpFlow(nn.Module):
         means = [m * torch.ones(self.C, device=m.device) for m in self.mean_shifts]
         return means, covs
 
+    def _class_table(self, device):
+        """The class scales as a device tensor (uploaded once per device: no host round trip per loss evaluation)."""
+        t = self.__dict__.get("_classes_dev")
+        if t is None or t.device != device:
+            t = torch.tensor(np.asarray(self.classes), device=device)
+            self.__dict__["_classes_dev"] = t
+        return t
+
+    def _class_loglik(self, z, label):
+        """flow_model.py:143-160: (log-density of every sample under every class prior [n, cls], the label mask, the
+        log-density `ll` the objective uses).  The reference ASSIGNS ll[label == c] per class, and the 'X' (label 0) rows are
+        written again by the second loop, so a label-0 sample ends with the standard-normal log-density even when 0 is one
+        of the classes.  No host tests on device data here (the reference's `any()` branch is a `where`)."""
+        label = label.to(z.device)
+        means, covs = self._shifted(z.device)
+        ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
+        mask_label = self._class_table(z.device)[None, :] == label.reshape(-1, 1)
+        ll = torch.zeros(z.shape[0], device=z.device)
+        for i in range(len(self.classes)):
+            ll = torch.where(mask_label[:, i], ll_all[:, i], ll)
+        ll = torch.where(label == 0, Gaussian.logp(None, None, z), ll)
+        return ll_all, mask_label, ll
+
     def calculate_loss(self, epses, logdet, pixels, label):
         objective = logdet.clone()
         z = epses[-1] if isinstance(epses, (list, tuple)) else epses
@@ -366,20 +389,7 @@ class InterpFlow(nn.Module):
             label = torch.Tensor(label)
         assert z.shape[0] == label.shape[0], 'need one class label per datapoint'
         assert len(label.shape) == 1, 'labels must be one dimensional'
-        label = label.to(z.device)
-        means, covs = self._shifted(z.device)
-        # log-density of every sample under every class prior: one HIP pass per class (flow_model.py:156-160)
-        ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
-        classes = torch.tensor(np.tile(self.classes, reps=z.shape[0]).reshape((z.shape[0], -1)), device=z.device)
-        mask_label = (classes == label.reshape(-1, 1))
-        # flow_model.py:143-160 ASSIGNS: ll[label == c] = class-c log-density, and the 'X' (label 0) rows are written again by
-        # the second loop, so a label-0 sample ends with the standard-normal log-density even when 0 is one of the classes
-        ll = torch.zeros(z.shape[0], device=z.device)
-        for i in range(len(self.classes)):
-            ll = torch.where(mask_label[:, i], ll_all[:, i], ll)
-        is_x = label == 0
-        if bool(is_x.any()):
-            ll = torch.where(is_x, Gaussian.logp(None, None, z), ll)
+        ll_all, mask_label, ll = self._class_loglik(z, label)
         ll_ib = ll_all / float(pixels)
         ll_ib = torch.log_softmax(ll_ib, dim=1)
         ll_ib = torch.masked_select(ll_ib, mask_label)

@@ -24,6 +24,9 @@ from . import train_ops as T
 from .synth import N_RRDB_CH
 
 
+FUSED_LEVELS = True      # encode on the level drivers of train_fused.py when they apply (tests switch it off to compare)
+
+
 # ------------------------------------------------------------------------------------------------ ActNorm
 def actnorm_init(an, x_cl):
     """FlowActNorms.py:29-43 on a channels-last tensor [B,h,w,C]."""
@@ -196,6 +199,12 @@ def run(fu, src, rrdbResults, logdet, test_input_size, decode):
         return rings[level]
 
     ld = _as_logdet(logdet, B, src.device)
+    if not decode and FUSED_LEVELS:
+        from . import train_fused
+        if train_fused.usable(fu, feats):
+            out = train_fused.run_encode(fu, src, feats, ld)
+            if out is not None:
+                return out
     z = src.float().permute(0, 2, 3, 1)
     kinds = [k for k, _ in fu._kinds]
     if not decode:

@@ -1,0 +1,397 @@
+"""Gradient-enabled encode of the flow on the level drivers of the HIP library (training path, second version).
+
+`train_flow.run` evaluates the stack layer by layer as a torch graph: about 40 autograd nodes and a few hundred small
+launches per FlowStep, and the GPU idles while Python and autograd issue them (profiles/r02_train_kernel_stats.csv).
+Here one `torch.autograd.Function` covers a whole flow level (2 + 16 FlowSteps): its forward is ONE library call
+(`ifl_train_level_fwd`) after one re-layout launch for all of the level's convolution weights (`ifl_pack_table`), its
+backward one call (`ifl_train_level_bwd`) plus one launch that brings the dense weight gradients into the parameters'
+layout.  Activations, packed weights, gradients and partial sums live in an arena that is allocated once per shape
+(`LevelPlan`); the descriptors that carry its pointers are built once.  What stays in torch: the squeeze between levels, the
+composition of each step's per-pixel affine map from its ActNorm and LU parameters (batched over the level's steps, so
+autograd handles the chain rule to bias / logs / l / u / log_s in a handful of nodes), and five reductions of per-block
+partial sums per level.
+
+Used by `train_flow.run` for the encode direction whenever it applies (`usable`): every ActNorm initialised, conditioning
+features that need no gradient (frozen encoder), C in {12, 48}, a free arena.  Everything else (decode with gradients, the
+trained-encoder case, the data-dependent ActNorm initialisation pass) stays on the layer-by-layer path.
+
+Reference: FlowUpsamplerNet.encode (FlowUpsamplerNet.py:217-260), FlowStep.normal_flow (FlowStep.py:114-151),
+CondAffineSeparatedAndCond.forward (FlowAffineCouplingsAblation.py:159-208), flow.Conv2d / Conv2dZeros (flow.py:25-82),
+ActNorm2d (FlowActNorms.py:45-97), InvertibleConv1x1 (Permutations.py:76-123).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import hip
+from . import train_ops as T
+from .synth import N_RRDB_CH
+
+MAX_PLANS_PER_SHAPE = 4        # forwards whose backward is still due, per level and shape (each holds an arena)
+
+
+class IflTrainNet(Structure):
+    _fields_ = [(k, c_void_p) for k in ("w1", "w2", "w3", "w1t", "w2t", "w3t", "an1_bias", "an1_logs", "an2_bias", "an2_logs",
+                                        "bias3", "logs3", "p1", "a1", "p2", "a2", "hraw", "dW1", "dW2", "dW3", "an1_part",
+                                        "an2_part", "dlogs_part", "dbias_part", "ldpart")] + \
+               [(k, c_int32) for k in ("c0", "n", "hstride", "has_z1")]
+
+
+class IflTrainStep(Structure):
+    _fields_ = [(k, c_void_p) for k in ("M", "c", "dM_part", "z_in", "z_a", "z_mid", "z_out")] + \
+               [("cond", c_int32), ("pad_", c_int32), ("net", IflTrainNet * 2)]
+
+
+class IflTrainLevel(Structure):
+    _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch")] + \
+               [("eps", c_float), ("pad_", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
+                ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep))]
+
+
+PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode", "<i4"), ("cout_real", "<i4"),
+                       ("cout_pad", "<i4"), ("taps", "<i4"), ("real0", "<i4"), ("pad0", "<i4"), ("real1", "<i4"),
+                       ("pad1", "<i4"), ("a0", "<i4"), ("acnt", "<i4")])
+assert PACK_DTYPE.itemsize == 64
+PACK_FWD, PACK_TRANSPOSED, PACK_VECTOR, PACK_GRAD = 0, 1, 2, 3
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = hip.lib()
+    if not _bound:
+        L.ifl_pack_table.argtypes = [c_void_p, ctypes.c_int, c_int64, c_void_p]
+        L.ifl_pack_table.restype = ctypes.c_int
+        L.ifl_affine_px_blocks.argtypes = [c_int64]
+        L.ifl_affine_px_blocks.restype = c_int64
+        L.ifl_train_level_fwd.argtypes = [POINTER(IflTrainLevel), c_void_p]
+        L.ifl_train_level_fwd.restype = ctypes.c_int
+        L.ifl_train_level_bwd.argtypes = [POINTER(IflTrainLevel), c_void_p, c_void_p, c_void_p, c_void_p]
+        L.ifl_train_level_bwd.restype = ctypes.c_int
+        _bound = True
+    return L
+
+
+def _net_params(seq):
+    """The nine parameters of one coupling network, in the order the level function takes them."""
+    c1, c2, c3 = seq[0], seq[2], seq[4]
+    return [c1.weight, c1.actnorm.bias, c1.actnorm.logs, c2.weight, c2.actnorm.bias, c2.actnorm.logs, c3.weight, c3.bias, c3.logs]
+
+
+class LevelPlan:
+    """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
+
+    def __init__(self, steps, B, h, w, C, device):
+        L = _lib()
+        self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
+        self.busy = False
+        ns = len(self.steps)
+        self.cond = [hasattr(s, "affine") for s in self.steps]
+        nc = sum(self.cond)
+        ch = C // 2
+        self.ch = ch
+        aff = next((s.affine for s in self.steps if hasattr(s, "affine")), None)
+        self.eps = float(aff.affine_eps) if aff is not None else 0.0
+        # the encode direction with multReverse (FlowAffineCouplingsAblation.py:164-165,187-207): fAffine on [ch, C) first
+        # (its network reads z[:, :ch]), then fFeatures on all channels, both in the "divide" branch
+        self.nets = [("fAffine", ch, C - ch, True), ("fFeatures", 0, C, False)]
+        self.hstride = [T.pad32(2 * n) for _, _, n, _ in self.nets]
+        f32 = dict(dtype=torch.float32, device=device)
+
+        def zeros(*shape):
+            return torch.zeros(*shape, **f32)
+
+        nblk_a = int(L.ifl_affine_px_blocks(B * h * w))
+        nblk_an = int(L.ifl_an_relu_blocks(B, h, w))
+        nblk_c = int(L.ifl_coupling_blocks(h, w))
+        cin1 = [(32 if z1 else 0) + N_RRDB_CH for _, _, _, z1 in self.nets]
+        # ---- saved activations and gradients ----
+        self.M, self.c = zeros(ns, C, C), zeros(ns, C)
+        self.dM_part = zeros(ns, nblk_a, C * C + C)
+        self.z = zeros(ns + 2 * nc + 1, B, h, w, C)                    # z_in of every step, z_a / z_mid of conditional ones, the output
+        self.act = zeros(max(nc, 1), 2, 4, B, h + 2, w + 2, 64)        # p1, a1, p2, a2 per (step, network)
+        self.hraw = [zeros(max(nc, 1), B, h + 2, w + 2, hs) for hs in self.hstride]
+        self.an_part = zeros(max(nc, 1), 2, 2, nblk_an, 128)
+        self.cpl_part = [zeros(max(nc, 1), 2, B * nblk_c, 2 * n) for _, _, n, _ in self.nets]      # (d logs3 | d bias3)
+        self.ldpart = zeros(max(nc, 1), 2, B, nblk_c)
+        # packed weights / dense gradients / parameter-layout gradients: one flat buffer each
+        sizes_w, sizes_g, sizes_r = [], [], []
+        for i, (_, _, n, z1) in enumerate(self.nets):
+            hs = self.hstride[i]
+            sizes_w.append([64 * cin1[i] * 9, 64 * 64, hs * 64 * 9, (32 * 64 * 9) if z1 else 0, 64 * 64, 64 * hs * 9, hs])
+            sizes_g.append([64 * cin1[i] * 9, 64 * 64, hs * 64 * 9])
+            cin_real = (ch if z1 else 0) + N_RRDB_CH
+            sizes_r.append([64 * cin_real * 9, 64 * 64, 2 * n * 64 * 9])
+        per_w, per_g, per_r = (sum(sum(x) for x in s) for s in (sizes_w, sizes_g, sizes_r))
+        self.wbuf, self.dW, self.graw = zeros(max(nc, 1) * per_w), zeros(max(nc, 1) * per_g), zeros(max(nc, 1) * per_r)
+        # ---- scratch ----
+        self.z1ring, self.dz1ring = zeros(B, h + 2, w + 2, 32), zeros(B, h + 2, w + 2, 32)
+        self.dzs = zeros(4, B, h, w, C)
+        self.dh = [zeros(B, h + 2, w + 2, hs) for hs in self.hstride]
+        self.d64 = zeros(2, B, h + 2, w + 2, 64)
+        self.dz_in = zeros(B, h, w, C)
+        self.ft = None                                                  # bound per call (pointer written into the level struct)
+
+        # ---- descriptors ----
+        self.c_steps = (IflTrainStep * ns)()
+        pack_rows, grad_rows = [], []
+        self.param_slices = []                                          # per parameter of the function: how to find its gradient
+        zi, ci = 0, 0
+        wo = go = ro = 0
+        ptr = lambda t: t.data_ptr()
+        self.params = []
+        for s, step in enumerate(self.steps):
+            S = self.c_steps[s]
+            S.M, S.c, S.dM_part = ptr(self.M[s]), ptr(self.c[s]), ptr(self.dM_part[s])
+            S.z_in = ptr(self.z[zi])
+            S.cond = 1 if self.cond[s] else 0
+            if not self.cond[s]:
+                S.z_a = ptr(self.z[zi + 1])
+                zi += 1
+                continue
+            S.z_a, S.z_mid, S.z_out = ptr(self.z[zi + 1]), ptr(self.z[zi + 2]), ptr(self.z[zi + 3])
+            zi += 3
+            for i, (name, c0, n, z1) in enumerate(self.nets):
+                N = S.net[i]
+                seq = getattr(step.affine, name)
+                prm = _net_params(seq)
+                self.params += prm
+                hs = self.hstride[i]
+                w1, an1b, an1l, w2, an2b, an2l, w3, b3, l3 = prm
+                assert tuple(w1.shape) == (64, (ch if z1 else 0) + N_RRDB_CH, 3, 3) and tuple(w2.shape) == (64, 64, 1, 1)
+                assert tuple(w3.shape) == (2 * n, 64, 3, 3) and b3.numel() == 2 * n and l3.numel() == 2 * n
+                assert an1b.numel() == 64 and an2l.numel() == 64
+                offs = np.cumsum([0] + sizes_w[i])
+                wv = [self.wbuf[wo + offs[k]: wo + offs[k + 1]] for k in range(7)]
+                wo += int(offs[-1])
+                N.w1, N.w2, N.w3 = ptr(wv[0]), ptr(wv[1]), ptr(wv[2])
+                N.w1t = ptr(wv[3]) if z1 else None
+                N.w2t, N.w3t, N.bias3 = ptr(wv[4]), ptr(wv[5]), ptr(wv[6])
+                N.an1_bias, N.an1_logs, N.an2_bias, N.an2_logs, N.logs3 = ptr(an1b), ptr(an1l), ptr(an2b), ptr(an2l), ptr(l3)
+                a = self.act[ci, i]
+                N.p1, N.a1, N.p2, N.a2 = ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3])
+                N.hraw = ptr(self.hraw[i][ci])
+                goffs = np.cumsum([0] + sizes_g[i])
+                gv = [self.dW[go + goffs[k]: go + goffs[k + 1]] for k in range(3)]
+                go += int(goffs[-1])
+                N.dW1, N.dW2, N.dW3 = ptr(gv[0]), ptr(gv[1]), ptr(gv[2])
+                N.an1_part, N.an2_part = ptr(self.an_part[ci, i, 0]), ptr(self.an_part[ci, i, 1])
+                N.dlogs_part, N.dbias_part = ptr(self.cpl_part[i][ci, 0]), ptr(self.cpl_part[i][ci, 1])
+                N.ldpart = ptr(self.ldpart[ci, i])
+                N.c0, N.n, N.hstride, N.has_z1 = c0, n, hs, 1 if z1 else 0
+                r0, p0 = (ch, 32) if z1 else (0, 0)
+                common1 = dict(cout_real=64, cout_pad=64, taps=9, real0=r0, pad0=p0, real1=N_RRDB_CH, pad1=N_RRDB_CH)
+                common2 = dict(cout_real=64, cout_pad=64, taps=1, real0=64, pad0=64, real1=0, pad1=0)
+                common3 = dict(cout_real=2 * n, cout_pad=hs, taps=9, real0=64, pad0=64, real1=0, pad1=0)
+                pack_rows += [dict(src=ptr(w1), dst=ptr(wv[0]), nelem=wv[0].numel(), mode=PACK_FWD, **common1),
+                              dict(src=ptr(w2), dst=ptr(wv[1]), nelem=wv[1].numel(), mode=PACK_FWD, **common2),
+                              dict(src=ptr(w3), dst=ptr(wv[2]), nelem=wv[2].numel(), mode=PACK_FWD, **common3),
+                              dict(src=ptr(w2), dst=ptr(wv[4]), nelem=wv[4].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=64, **common2),
+                              dict(src=ptr(w3), dst=ptr(wv[5]), nelem=wv[5].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=64, **common3),
+                              dict(src=ptr(b3), dst=ptr(wv[6]), nelem=hs, mode=PACK_VECTOR, cout_real=2 * n, cout_pad=hs, taps=1)]
+                if z1:
+                    pack_rows.append(dict(src=ptr(w1), dst=ptr(wv[3]), nelem=wv[3].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=32, **common1))
+                roffs = np.cumsum([0] + sizes_r[i])
+                rv = [self.graw[ro + roffs[k]: ro + roffs[k + 1]] for k in range(3)]
+                ro += int(roffs[-1])
+                grad_rows += [dict(src=ptr(gv[0]), dst=ptr(rv[0]), nelem=rv[0].numel(), mode=PACK_GRAD, **common1),
+                              dict(src=ptr(gv[1]), dst=ptr(rv[1]), nelem=rv[1].numel(), mode=PACK_GRAD, **common2),
+                              dict(src=ptr(gv[2]), dst=ptr(rv[2]), nelem=rv[2].numel(), mode=PACK_GRAD, **common3)]
+                self.param_slices += [("w", rv[0], w1.shape), ("an", (ci, i, 0, 0), an1b.shape), ("an", (ci, i, 0, 1), an1l.shape),
+                                      ("w", rv[1], w2.shape), ("an", (ci, i, 1, 0), an2b.shape), ("an", (ci, i, 1, 1), an2l.shape),
+                                      ("w", rv[2], w3.shape), ("cpl", (i, ci, 1), b3.shape), ("cpl", (i, ci, 0), l3.shape)]
+            ci += 1
+        assert zi == self.z.shape[0] - 1
+        self.z_first, self.z_last = self.z[0], self.z[zi]
+        self.param_ptrs = tuple(p.data_ptr() for p in self.params)
+
+        def table(rows):
+            if not rows:
+                return None, 0, 0
+            arr = np.zeros(len(rows), dtype=PACK_DTYPE)
+            for k, r in enumerate(rows):
+                for key, v in r.items():
+                    arr[k][key] = v
+            return torch.from_numpy(arr.view(np.uint8)).to(device), len(rows), int(arr["nelem"].max())
+        self.pack_tab = table(pack_rows)
+        self.grad_tab = table(grad_rows)
+
+        lv = IflTrainLevel()
+        lv.B, lv.h, lv.w, lv.C, lv.ch, lv.nsteps, lv.branch, lv.ft_ch = B, h, w, C, ch, ns, 1, N_RRDB_CH
+        lv.eps = self.eps
+        lv.z1ring, lv.dz1ring = ptr(self.z1ring), ptr(self.dz1ring)
+        for k in range(4):
+            lv.dz[k] = ptr(self.dzs[k])
+        for k in range(2):
+            lv.dh[k] = ptr(self.dh[k])
+            lv.d64[k] = ptr(self.d64[k])
+        lv.steps = ctypes.cast(self.c_steps, POINTER(IflTrainStep))
+        self.level = lv
+
+    def matches(self, params):
+        return len(params) == len(self.param_ptrs) and all(p.data_ptr() == q for p, q in zip(params, self.param_ptrs))
+
+    def run_table(self, tab):
+        t, n, mx = tab
+        if n:
+            hip.check(_lib().ifl_pack_table(hip._ptr(t), n, mx, hip._stream()), "ifl_pack_table")
+
+
+class _Lease:
+    """Frees the plan when the backward has run or the graph that holds it is dropped."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.busy = False
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
+class _LevelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, ft_ring, z, M_all, c_all, *params):
+        L = _lib()
+        plan.busy = True
+        ctx.lease = _Lease(plan)
+        ctx.ft_ring = ft_ring                           # the backward reads it (weight gradients of the first convolutions)
+        with torch.cuda.device(plan.device):
+            plan.z_first.copy_(z)
+            plan.M.copy_(M_all)
+            plan.c.copy_(c_all)
+            plan.level.ft = ft_ring.data_ptr() if ft_ring is not None else None
+            plan.run_table(plan.pack_tab)
+            hip.check(L.ifl_train_level_fwd(ctypes.byref(plan.level), hip._stream()), "ifl_train_level_fwd")
+            ld = plan.ldpart.sum(dim=(0, 1, 3))
+        return plan.z_last.clone(), ld
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gz, gld):
+        plan = ctx.lease.plan
+        assert plan is not None, "the level's arena was released before its backward ran"
+        L = _lib()
+        f32 = dict(dtype=torch.float32, device=plan.device)
+        gz = torch.zeros(plan.z_last.shape, **f32) if gz is None else gz.contiguous().float()
+        gld = torch.zeros(plan.B, **f32) if gld is None else gld.contiguous().float()
+        with torch.cuda.device(plan.device):
+            plan.level.ft = ctx.ft_ring.data_ptr() if ctx.ft_ring is not None else None
+            plan.dW.zero_()
+            hip.check(L.ifl_train_level_bwd(ctypes.byref(plan.level), hip._ptr(gz), hip._ptr(gld), hip._ptr(plan.dz_in), hip._stream()),
+                      "ifl_train_level_bwd")
+            plan.run_table(plan.grad_tab)
+            C = plan.C
+            dMc = plan.dM_part.sum(dim=1)                                  # [steps, C*C + C]
+            an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
+            cpl = [t.sum(dim=2) for t in plan.cpl_part]                    # per network slot: [cond steps, (logs3 | bias3), 2n]
+            grads = []
+            for kind, where, shape in plan.param_slices:
+                if kind == "w":
+                    grads.append(where.view(shape).clone())
+                elif kind == "an":
+                    s, i, a, k = where
+                    grads.append(an[s, i, a, k * 64:(k + 1) * 64].reshape(shape))
+                else:
+                    i, s, k = where
+                    grads.append(cpl[i][s, k].reshape(shape))
+            dz = plan.dz_in.clone()
+        ctx.lease.release()
+        return (None, None, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
+
+
+def _affine_maps(steps, C, pixels):
+    """Per step: M = W diag(exp(logs)), c = M bias (ActNorm2d then InvertibleConv1x1), batched over the level's steps; and the
+    level's data-independent log-det  pixels * sum_steps (sum logs + log|det W|)  (FlowActNorms.py:69-85, Permutations.py:76-101)."""
+    dev = steps[0].actnorm.bias.device
+    logs = torch.stack([s.actnorm.logs.reshape(-1) for s in steps])
+    bias = torch.stack([s.actnorm.bias.reshape(-1) for s in steps])
+    ics = [s.invconv for s in steps]
+    if all(ic.LU for ic in ics):
+        l_mask = torch.tril(torch.ones(C, C, device=dev), -1)
+        eye = torch.eye(C, device=dev)
+        l = torch.stack([ic.l for ic in ics]) * l_mask + eye
+        log_s = torch.stack([ic.log_s for ic in ics])
+        sign_s = torch.stack([ic.sign_s for ic in ics])
+        u = torch.stack([ic.u for ic in ics]) * l_mask.t() + torch.diag_embed(sign_s * torch.exp(log_s))
+        W = torch.matmul(torch.stack([ic.p for ic in ics]), torch.matmul(l, u))
+        dl = log_s.sum()
+    else:
+        from .train_flow import invconv_weight
+        ws, dls = zip(*(invconv_weight(ic, False) for ic in ics))
+        W, dl = torch.stack(ws), torch.stack(dls).sum()
+    M = W * torch.exp(logs)[:, None, :]
+    c = torch.matmul(M, bias[:, :, None]).squeeze(-1)
+    return M, c, (logs.sum() + dl) * pixels
+
+
+def usable(fu, feats) -> bool:
+    """Whether the fused level path applies to this gradient-enabled encode."""
+    kinds = [k for k, _ in fu._kinds]
+    if any(k not in ("squeeze", "step0", "stepc") for k in kinds):
+        return False
+    for ft in feats.values():
+        if ft.requires_grad:
+            return False                      # gradients towards the conditioning encoder: the layer-by-layer path has them
+    from .training import _uninitialised_actnorms
+    if _uninitialised_actnorms(fu.layers):
+        return False                          # data-dependent ActNorm initialisation is still due
+    return all(c in (12, 48) for k, c in fu._kinds if k != "squeeze")
+
+
+def _plan_for(fu, level, steps, B, h, w, C, device, params):
+    cache = fu.__dict__.setdefault("_train_plans", {})
+    key = (level, B, h, w, C, str(device))
+    plans = cache.setdefault(key, [])
+    plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
+    for p in plans:
+        if not p.busy:
+            return p
+    if len(plans) >= MAX_PLANS_PER_SHAPE:
+        return None
+    p = LevelPlan(steps, B, h, w, C, device)
+    plans.append(p)
+    return p
+
+
+def run_encode(fu, src, feats, ld):
+    """FlowUpsamplerNet.encode with gradients on the level drivers.  src: NCHW float32 on the GPU; feats: {level: NCHW
+    conditioning map}; ld: [B] log-det so far.  Returns (z NCHW, logdet [B]) or None when no arena is free."""
+    from .train_flow import squeeze_cl
+    levels, cur = [], None
+    for layer, (kind, C) in zip(fu.layers, fu._kinds):
+        if kind == "squeeze":
+            cur = []
+            levels.append((C, cur))
+        else:
+            cur.append(layer)
+    z = src.float().permute(0, 2, 3, 1)
+    B = src.shape[0]
+    plans = []
+    h, w = z.shape[1], z.shape[2]
+    for lv, (C, steps) in enumerate(levels, start=1):
+        h, w = h // 2, w // 2
+        params = [p for s in steps if hasattr(s, "affine") for name in ("fAffine", "fFeatures") for p in _net_params(getattr(s.affine, name))]
+        plan = _plan_for(fu, lv, steps, B, h, w, C, src.device, params)
+        if plan is None:
+            return None
+        plans.append((plan, params, steps, C, h, w, lv))
+    for plan, params, steps, C, h, w, lv in plans:
+        z = squeeze_cl(z).contiguous()
+        ft = feats.get(lv)
+        ft_ring = None
+        if any(plan.cond):
+            assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h, w), (lv, None if ft is None else tuple(ft.shape))
+            ft_ring = T.to_ring(ft.detach().float())
+        M, c, ld_const = _affine_maps(steps, C, h * w)
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, z, M, c, *params)
+        ld = ld + ld_lv + ld_const
+    return z.permute(0, 3, 1, 2).contiguous(), ld

@@ -116,6 +116,58 @@ def test_training_step_values_and_gradients_vs_oracle():
     assert rel(z2, z) < 1e-4 and rel(ld2, ld) < 1e-4 and rel(nll2, nll) < 1e-4
 
 
+def test_fused_level_training_vs_oracle():
+    """The level drivers (train_fused.py: ifl_train_level_fwd / _bwd, ifl_pack_table) -- the path a training step takes when
+    the conditioning needs no gradient -- against CPU autograd of the oracle: values and every parameter gradient; twice, to
+    show that the arena is reusable, and against the layer-by-layer path of the same module."""
+    from interflow_amd import train_flow
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 2, 16
+    x = torch.from_numpy(synth.synth_images(81, B, H, H))
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(82, B, H, H).items()}
+    labels = torch.tensor([2, 4])
+    zr, ldr, nllr, ibr, lossr, leaves, _ = _oracle_step(sd_np, x, feats, labels)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    fd = {k: v.to(dev()) for k, v in feats.items()}
+    named = dict(model.named_parameters())
+    fu = model.arch.flowUpsamplerNet
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        z, nll, ld, ll_ib = model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
+        loss = nll.mean() + 1.0 * (-ll_ib.mean())
+        loss.backward()
+        return z.detach(), nll.detach(), ld.detach(), ll_ib.detach(), loss.detach()
+
+    for rnd in range(2):
+        z, nll, ld, ll_ib, loss = step()
+        plans = fu.__dict__.get("_train_plans", {})
+        assert len(plans) == 2 and all(len(v) == 1 and not v[0].busy for v in plans.values()), "the level drivers did not run"
+        assert rel(z, zr) < 1e-4 and rel(ld, ldr) < 1e-4 and rel(nll, nllr) < 1e-4 and rel(ll_ib, ibr) < 1e-3 and rel(loss, lossr) < 1e-4
+        worst, checked = ("", 0.0), 0
+        for key, ref in leaves.items():
+            name = key.replace("flow_upsampler.", "arch.flowUpsamplerNet.") if key.startswith("flow_upsampler.") else key
+            assert named[name].grad is not None, key
+            worst = max(worst, (key, rel(named[name].grad, ref.grad)), key=lambda t: t[1])
+            checked += 1
+        print(f"round {rnd}: checked {checked} parameter gradients, worst {worst[0]}: {worst[1]:.2e}")
+        assert checked > 700 and worst[1] < 5e-4, worst
+    fused = {k: p.grad.clone() for k, p in named.items() if p.grad is not None}
+    train_flow.FUSED_LEVELS = False
+    try:
+        z2, nll2, ld2, _, loss2 = step()
+    finally:
+        train_flow.FUSED_LEVELS = True
+    assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
+    for k, g in fused.items():
+        assert rel(named[k].grad, g) < 2e-4, k
+    # a forward whose graph is dropped gives its arena back
+    model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
+    assert all(not p.busy for v in fu._train_plans.values() for p in v)
+
+
 def test_decode_with_gradients_vs_oracle():
     """The gradient-enabled decode (train.py:94, the LR-consistency branch) against CPU autograd of the oracle."""
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)

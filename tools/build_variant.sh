@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_exp/obj_$SUFFIX
-for f in api layout pointwise conv1 conv1x conv3 conv3w convg rrdb train_glue; do
+for f in api layout pointwise conv1 conv1x conv3 conv3w convg rrdb train_glue train_fused; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $EXTRA -c interflow_amd/csrc/$f.hip -o gpurun_exp/obj_$SUFFIX/$f.o &
 done
 wait
