@@ -33,6 +33,22 @@ from .synth import N_RRDB_CH
 
 MAX_PLANS_PER_SHAPE = 4        # forwards whose backward is still due, per level and shape (each holds an arena)
 
+# Inside `accumulate_into_grad()` (training.train_step wraps loss.backward() in it) the level functions add the parameter
+# gradients straight into the parameters' existing .grad tensors with one multi-tensor add per level and hand autograd None
+# for them, instead of returning ~290 tensors per level that autograd clones or adds one by one.  Off by default: a plain
+# `torch.autograd.grad` / `backward` keeps the usual semantics.
+_direct_grad = False
+
+
+class accumulate_into_grad:
+    def __enter__(self):
+        global _direct_grad
+        self.prev, _direct_grad = _direct_grad, True
+
+    def __exit__(self, *exc):
+        global _direct_grad
+        _direct_grad = self.prev
+
 
 class IflTrainNet(Structure):
     _fields_ = [(k, c_void_p) for k in ("w1", "w2", "w3", "w1t", "w2t", "w3t", "an1_bias", "an1_logs", "an2_bias", "an2_logs",
@@ -293,16 +309,24 @@ class _LevelFn(torch.autograd.Function):
             dMc = plan.dM_part.sum(dim=1)                                  # [steps, C*C + C]
             an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
             cpl = [t.sum(dim=2) for t in plan.cpl_part]                    # per network slot: [cond steps, (logs3 | bias3), 2n]
-            grads = []
-            for kind, where, shape in plan.param_slices:
+            grads, dst, src = [], [], []
+            for (kind, where, shape), p in zip(plan.param_slices, plan.params):
                 if kind == "w":
-                    grads.append(where.view(shape).clone())
+                    g = where.view(shape)
                 elif kind == "an":
                     s, i, a, k = where
-                    grads.append(an[s, i, a, k * 64:(k + 1) * 64].reshape(shape))
+                    g = an[s, i, a, k * 64:(k + 1) * 64].reshape(shape)
                 else:
                     i, s, k = where
-                    grads.append(cpl[i][s, k].reshape(shape))
+                    g = cpl[i][s, k].reshape(shape)
+                if _direct_grad and p.grad is not None and p.grad.dtype == torch.float32:
+                    dst.append(p.grad)
+                    src.append(g)
+                    grads.append(None)
+                else:
+                    grads.append(g.clone() if kind == "w" else g)
+            if dst:
+                torch._foreach_add_(dst, src)
             dz = plan.dz_in.clone()
         ctx.lease.release()
         return (None, None, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)

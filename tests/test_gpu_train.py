@@ -163,6 +163,15 @@ def test_fused_level_training_vs_oracle():
     assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
+    # train_step's mode: the level functions add into existing .grad tensors themselves (one multi-tensor add per level)
+    from interflow_amd.train_fused import accumulate_into_grad
+    for p in named.values():
+        p.grad = torch.full_like(p, 0.5) if p.requires_grad else None
+    z3, nll3, ld3, ib3 = model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
+    with accumulate_into_grad():
+        (nll3.mean() - ib3.mean()).backward()
+    for k, g in fused.items():
+        assert rel(named[k].grad - 0.5, g) < 1e-5, k
     # a forward whose graph is dropped gives its arena back
     model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
     assert all(not p.busy for v in fu._train_plans.values() for p in v)
