@@ -1,6 +1,8 @@
 // api.hip -- the C ABI of libinterflow_hip.so (see include/interflow_hip.h) and the host-side drivers that walk
 // FlowUpsamplerNet.layers natively (no Python dispatch per layer, no allocation, no synchronisation).
 #include "ifl_common.h"
+#include <map>
+#include <tuple>
 
 #include <cstdarg>
 #include <cstdio>
@@ -106,12 +108,12 @@ extern "C" int64_t ifl_step_field_off(int C, int field)
 
 // ---- tiling ---------------------------------------------------------------------------------------------------
 // Pick the band width that minimises (MFMA lane slots, then staged patch pixels) subject to the LDS patch bound.
-IflGeom ifl_choose_geom(int H, int W)
+static IflGeom choose_geom_uncached(int H, int W, int tpx)
 {
     IflGeom best{};
     double best_cost = -1;
     for (int bw = 1; bw <= W && bw <= 256; ++bw) {
-        IflGeom g{H, W, bw, ifl_cdiv(W, bw), ifl_cdiv(H * bw, IFL_MT), 0};
+        IflGeom g{H, W, bw, ifl_cdiv(W, bw), ifl_cdiv(H * bw, tpx), 0, tpx};
         g.ntiles = g.nbands * g.tiles_per_band;
         bool ok = true;
         double patch = 0;
@@ -124,10 +126,24 @@ IflGeom ifl_choose_geom(int H, int W)
             patch += tl.PP;
         }
         if (!ok) continue;
-        double cost = (double)active * IFL_MT * 8.0 + patch;
+        double cost = (double)active * tpx * 8.0 + patch;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }
     }
     return best;
+}
+
+// Memoised: the per-operator entry points (ifl_conv2d, ifl_conv2d_wgrad) ask for a plane's tiling on every call, and the
+// training drivers make about a thousand such calls per step.
+IflGeom ifl_choose_geom(int H, int W, int tpx)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, IflGeom> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(H, W, tpx);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cache.size() > 4096) cache.clear();
+    return cache[key] = choose_geom_uncached(H, W, tpx);
 }
 
 // ---- workspace ------------------------------------------------------------------------------------------------

@@ -19,7 +19,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <int MT, int TAPS>
+// HALF: a tile of 64 pixels instead of 128 -- waves (w & 1) own 32 pixels each, waves (w >> 1) split the K loop (k-steps
+// {0,1} / {2,3} of every chunk and tap) and add their halves through LDS.  Twice the workgroups of half the length for
+// launches that would leave most CUs idle (the encoder's 40x40 planes at batch 8: 104 workgroups).  The full form keeps the
+// same two partial sums in two accumulator sets and adds them last, so both forms give the same bits and the choice may
+// depend on the batch size without breaking batch invariance.
+template <int MT, int TAPS, bool HALF>
 __global__ __launch_bounds__(256, 2)
 void convg_kernel(IflConvArgs a)
 {
@@ -32,6 +37,8 @@ void convg_kernel(IflConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
+    const int pg = HALF ? (wave & 1) : wave;                      // 32-pixel group of the tile
+    const int kh = HALF ? (wave >> 1) : 0;                        // K half of this wave
     const int W2 = g.W + 2;
     const int64_t plane = (int64_t)(g.H + 2) * W2;
 
@@ -39,12 +46,12 @@ void convg_kernel(IflConvArgs a)
     int a0;
     int64_t opix;
     {
-        int idx = t.s + wave * 32 + j;
-        bool valid = idx < t.npx;
+        int idx = t.s + pg * 32 + j;
+        bool valid = idx < t.npx && pg * 32 + j < g.tpx;
         int idc = valid ? idx : t.npx - 1;
         int ty = idc / t.bwb, tx = idc - ty * t.bwb;
         constexpr int HALO = TAPS == 9 ? 1 : 0;                   // 1x1: the patch still has the halo, read its centre
-        a0 = (((ty - t.y_first - 1 + (1 - HALO)) * t.PW + tx + (1 - HALO)) * IFL_CS + 4 * h) * 4;
+        a0 = (((ty - t.y_first - 1 + (1 - HALO)) * t.PW + tx + (1 - HALO)) * IFL_CS + 4 * h) * 4 + kh * 64;
         opix = valid ? ((int64_t)b * plane + (int64_t)(ty + 1) * W2 + t.x0 + tx + 1) : -1;
     }
 
@@ -57,17 +64,21 @@ void convg_kernel(IflConvArgs a)
     }
     const int q4 = (tid & 7) * 4;
 
-    f32x16 acc[MT];
+    constexpr int NH = HALF ? 1 : 2;                              // partial sums a wave holds: k-steps {0,1} and {2,3}
+    f32x16 acc[NH][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int n = 0; n < NH; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     const int nchunks = a.nchunks;
     constexpr int KQ = 4;                                         // k-steps of 8 channels per 32-channel chunk
+    constexpr int KQW = HALF ? 2 : 4;                             // ... of which this wave multiplies KQW
     // weights: one record per 32 output channels, [chunk][tap][kq][64 lanes x 4]; this workgroup reads records grp*MT .. +MT
     const int64_t wrec = (int64_t)nchunks * (TAPS * KQ * 256);
-    const float* wl = a.w + (int64_t)grp * MT * wrec + lane * 4;
+    const float* wl = a.w + (int64_t)grp * MT * wrec + lane * 4 + kh * (2 * 256);
 
     auto chunk_src = [&](int cc, int i) -> const float* {         // source pointer of staging slot i for chunk cc
         int s = 0, c = cc;
@@ -92,7 +103,7 @@ void convg_kernel(IflConvArgs a)
             for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(cc + 1, i);
         }
         const float* wc = wl + (int64_t)cc * (TAPS * KQ * 256);
-        constexpr int ITERS = TAPS * KQ;
+        constexpr int ITERS = TAPS * KQW;
         f32x4 wq[2][MT], xb[2];
 #pragma unroll
         for (int m = 0; m < MT; ++m) wq[0][m] = *(const f32x4*)(wc + m * wrec);
@@ -100,17 +111,40 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             if (it + 1 < ITERS) {
-                const int tap = (it + 1) / KQ, kq = (it + 1) % KQ;
+                const int tap = (it + 1) / KQW, kq = (it + 1) % KQW;
                 const int tapoff = TAPS == 9 ? ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4) : 0;
                 xb[(it + 1) & 1] = *(const f32x4*)((const char*)lds + a0 + tapoff + kq * 32);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + m * wrec + (it + 1) * 256);
+                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + m * wrec + (tap * KQ + kq) * 256);
             }
+            const int half = HALF ? 0 : ((it % KQW) >> 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma32(wq[it & 1][m][e], xb[it & 1][e], acc[m]);
+                for (int m = 0; m < MT; ++m) acc[half][m] = mfma32(wq[it & 1][m][e], xb[it & 1][e], acc[half][m]);
         }
+    }
+
+    // the two halves of the K loop
+    f32x16 tot[MT];
+    if constexpr (!HALF) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) tot[m] = acc[0][m] + acc[NH - 1][m];
+    } else {
+        float* ex = lds + (pg * MT) * (16 * 64) + lane;
+        __syncthreads();                                          // every wave's reads of the last patch are over
+        if (kh == 1) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[(m * 16 + r) * 64] = acc[0][m][r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[m][r] = acc[0][m][r] + ex[(m * 16 + r) * 64];
     }
 
     if (opix < 0) return;
@@ -121,7 +155,7 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int c = cbase + m * 32 + gq * 8;
-            f32x4 v = {acc[m][gq * 4], acc[m][gq * 4 + 1], acc[m][gq * 4 + 2], acc[m][gq * 4 + 3]};
+            f32x4 v = {tot[m][gq * 4], tot[m][gq * 4 + 1], tot[m][gq * 4 + 2], tot[m][gq * 4 + 3]};
             if (a.bias) {
                 f32x4 bb = *(const f32x4*)(a.bias + c);
 #pragma unroll
@@ -155,13 +189,25 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
     IFL_CHECK_ARG(a.cout % 32 == 0 && a.cout > 0, IFL_EINVAL, "convg: Cout=%d is not a multiple of 32", a.cout);
     IFL_CHECK_ARG(a.taps == 9 || a.taps == 1, IFL_EINVAL, "convg: taps=%d", a.taps);
     IFL_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2 && a.nchunks >= 1, IFL_EINVAL, "convg: sources");
+    IFL_CHECK_ARG(a.g.tpx == IFL_MT, IFL_EINVAL, "convg: tiling of %d pixels per tile", a.g.tpx);
+    // fewer workgroups than 1.5 per CU even at 32 output channels each: 64-pixel tiles with the K loop split inside the
+    // workgroup (same bits, see the kernel)
+    if ((int64_t)a.g.ntiles * B * (a.cout / 32) < 384) {
+        IflConvArgs h = a;
+        h.g = ifl_choose_geom(a.g.H, a.g.W, IFL_MT / 2);
+        dim3 grid(h.g.ntiles, B, a.cout / 32), block(256);
+        if (a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9, true>), grid, block, 0, st, h);
+        else hipLaunchKernelGGL((convg_kernel<1, 1, true>), grid, block, 0, st, h);
+        IFL_LAUNCH_CHECK();
+        return 0;
+    }
     // 64 output channels per workgroup when that still fills the chip, else 32 (twice the workgroups, half the latency each)
     const int mt = (a.cout % 64 == 0 && (int64_t)a.g.ntiles * B * (a.cout / 64) >= 256) ? 2 : 1;
     dim3 grid(a.g.ntiles, B, a.cout / (32 * mt)), block(256);
-    if (mt == 2 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<2, 9>), grid, block, 0, st, a);
-    else if (mt == 1 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9>), grid, block, 0, st, a);
-    else if (mt == 2) hipLaunchKernelGGL((convg_kernel<2, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((convg_kernel<1, 1>), grid, block, 0, st, a);
+    if (mt == 2 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<2, 9, false>), grid, block, 0, st, a);
+    else if (mt == 1 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9, false>), grid, block, 0, st, a);
+    else if (mt == 2) hipLaunchKernelGGL((convg_kernel<2, 1, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((convg_kernel<1, 1, false>), grid, block, 0, st, a);
     IFL_LAUNCH_CHECK();
     return 0;
 }

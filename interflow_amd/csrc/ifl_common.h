@@ -28,8 +28,9 @@ struct IflGeom {
     int H, W;             // plane size of this level
     int bw;               // band width (last band may be narrower)
     int nbands;
-    int tiles_per_band;   // ceil(H*bw / IFL_MT)
+    int tiles_per_band;   // ceil(H*bw / tpx)
     int ntiles;           // nbands * tiles_per_band   (= gridDim.x)
+    int tpx;              // pixels per tile: IFL_MT, or IFL_MT / 2 for the generic convolution's half-tile form
 };
 
 struct IflTile {          // decoded per workgroup (all fields wave-uniform)
@@ -46,9 +47,9 @@ static inline __host__ __device__ IflTile ifl_tile(const IflGeom& g, int tile) {
     t.x0 = band * g.bw;
     t.bwb = g.W - t.x0 < g.bw ? g.W - t.x0 : g.bw;
     t.npx = g.H * t.bwb;
-    t.s = chunk * IFL_MT;
+    t.s = chunk * g.tpx;
     t.active = t.s < t.npx;
-    int e = t.s + IFL_MT < t.npx ? t.s + IFL_MT : t.npx;
+    int e = t.s + g.tpx < t.npx ? t.s + g.tpx : t.npx;
     int r0 = t.s / t.bwb, r1 = (e - 1) / t.bwb;
     t.y_first = r0 - 1;
     t.nrows = r1 - r0 + 3;
@@ -170,7 +171,7 @@ struct IflConvArgs {
 int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
 int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,
                 int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st);
-IflGeom ifl_choose_geom(int H, int W);
+IflGeom ifl_choose_geom(int H, int W, int tpx = IFL_MT);
 
 int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out);     // base may be NULL (size query)
 void ifl_set_error(const char* fmt, ...);

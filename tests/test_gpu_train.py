@@ -53,6 +53,23 @@ def test_conv2d_ring_forward_and_gradients(cins, cout, k, B, h, w):
 
 
 # ----------------------------------------------------------------------------- whole flow: values and gradients
+@pytest.mark.parametrize("cin,cout,k,h,w", [(64, 32, 3, 40, 40), (192, 64, 3, 40, 40), (64, 64, 1, 20, 36), (96, 32, 3, 13, 7)])
+def test_conv2d_half_tile_form_gives_the_same_bits(cin, cout, k, h, w):
+    """ifl_conv2d switches to 64-pixel tiles with the K loop split inside the workgroup when a launch has few workgroups
+    (small planes at small batch); the full form keeps the same two partial sums, so a sample's result must not depend on
+    how many samples share the launch (batch invariance, bit for bit)."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    Bbig = 48
+    x = T.to_ring(torch.randn(Bbig, cin, h, w, generator=g)).to(dev())
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev())
+    with torch.no_grad():
+        big = T.conv2d_ring([x], [cin], wt)
+        small = T.conv2d_ring([x[:2].contiguous()], [cin], wt)
+    assert torch.equal(big[:2], small)
+    ref = F.conv2d(T.from_ring(x[:2], cin).cpu(), wt.cpu(), padding=k // 2)
+    assert rel(T.from_ring(small, cout), ref) < 2e-5
+
+
 from interflow_amd import synth                                   # noqa: E402
 from interflow_amd.flow_model import InterpFlow                   # noqa: E402
 from oracle import interflow_oracle as O                          # noqa: E402
