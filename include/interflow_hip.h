@@ -262,11 +262,16 @@ int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const
  *                        a0 + [0, acnt), fragment order with acnt outputs and cout_pad inputs
  *   IFL_PACK_VECTOR      dst[i] = i < cout_real ? src[i] : 0, i < nelem (padded bias)
  *   IFL_PACK_GRAD        dense gradient [cout_pad][pad0+pad1][taps] (ifl_conv2d_wgrad) -> the parameter's
- *                        [cout_real][real0+real1][taps]                                                              */
-enum { IFL_PACK_FWD = 0, IFL_PACK_TRANSPOSED = 1, IFL_PACK_VECTOR = 2, IFL_PACK_GRAD = 3 };
+ *                        [cout_real][real0+real1][taps]
+ *   IFL_PACK_WINO4       input channels [real0, real0 + 320) of a 3x3 weight [64][cin_src][3][3] -> U = G g G^T in the 6x6
+ *                        domain of Winograd F(4x4,3x3) (float64 arithmetic, rounded once), in the fragment order of the
+ *                        bulk kernel (conv1x.hip): 64*320*36 floats
+ * cin_src: the parameter's input-channel count (row length of src) when it differs from real0 + real1 (a weight of which
+ * only some input channels are packed); 0 = real0 + real1.                                                           */
+enum { IFL_PACK_FWD = 0, IFL_PACK_TRANSPOSED = 1, IFL_PACK_VECTOR = 2, IFL_PACK_GRAD = 3, IFL_PACK_WINO4 = 4 };
 typedef struct ifl_pack_desc {
     const float* src; float* dst; int64_t nelem;
-    int32_t mode, cout_real, cout_pad, taps, real0, pad0, real1, pad1, a0, acnt;
+    int32_t mode, cout_real, cout_pad, taps, real0, pad0, real1, pad1, a0, acnt, cin_src, pad_;
 } ifl_pack_desc;
 int ifl_pack_table(const ifl_pack_desc* table_dev, int n, int64_t max_elems, void* stream);
 
@@ -284,6 +289,7 @@ typedef struct ifl_train_net {
     float *dlogs_part, *dbias_part;              /* [B * ifl_coupling_blocks][2n] partial sums of d logs3 and of d bias3         */
     float *ldpart;                               /* [B][ifl_coupling_blocks] signed per-block sums of log scale                  */
     int32_t c0, n, hstride, has_z1;              /* coupling on channels [c0, c0+n); has_z1: the network also reads z[:, :ch]    */
+    int32_t p1_stride, pad_;                     /* pixel stride of p1 (64; 128 when p1 is a channel range of the bulk slab)     */
 } ifl_train_net;
 
 /* One FlowStep: z_a = M z_in + c (ActNorm2d then InvertibleConv1x1, M = W diag(exp(logs)), c = M bias), then -- cond != 0 --
@@ -305,7 +311,18 @@ typedef struct ifl_train_level {
     float *dh[2];                                /* scratch per network slot, ringed hstride channels, zero outside rows [0,2n)  */
     float *d64[2];                               /* scratch, ringed 64 channels, zero ring                                       */
     const ifl_train_step* steps;                 /* host array [nsteps]                                                          */
+    const float* raw;                            /* optional: ifl_train_bulk_conv1's slabs [conditional step][B][h+2][w+2][128]; then
+                                                    w1 of a network with z1 holds the 32 z1 input channels only and p1 = its z1
+                                                    taps + raw[.., 0:64]; a network without z1 has p1 = raw + 64, p1_stride 128  */
+    int64_t raw_step;                            /* floats between the slabs of consecutive conditional steps                    */
 } ifl_train_level;
+/* The conditioning part (320 channels of ft) of BOTH networks' first 3x3 convolution for all conditional steps of a level
+ * by the Winograd F(4x4,3x3) bulk kernel (the same kernel the inference path uses): raw[step][..][0:64] = fAffine's sums,
+ * [64:128] = fFeatures'.  wx: per step two IFL_PACK_WINO4 blocks (fAffine, fFeatures), wx_step floats apart, plus 4096
+ * floats of slack behind the last one.  vg: ifl_train_vg_floats(B, h, w) floats of scratch.                              */
+int64_t ifl_train_vg_floats(int B, int h, int w);
+int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float* wx, int64_t wx_step, int nsteps, float* raw,
+                         int64_t raw_step, int B, int h, int w, void* stream);
 int64_t ifl_affine_px_blocks(int64_t npx);
 int ifl_train_level_fwd(const ifl_train_level* L, void* stream);
 /* dz_out: gradient wrt the last step's output; dld: gradient wrt the per-sample log-det [B] (or NULL); dz_in: gradient wrt

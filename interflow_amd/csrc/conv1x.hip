@@ -156,7 +156,8 @@ void wino4_input_kernel(const float* __restrict__ ftP, float* __restrict__ vg, I
 template <int LVL>
 __global__ __launch_bounds__(512, 1)
 void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2all, int64_t h2_step_stride,
-                           const float* __restrict__ params, IflStepList steps, IflStepOff off, IflXGeom g, int ngroups, int ncombo)
+                           const float* __restrict__ params, IflStepList steps, IflStepOff off, IflXGeom g, int ngroups, int ncombo,
+                           int raw_both)
 {
     __shared__ __attribute__((aligned(16))) float lds[XLDS];              // V[0], V[1]; the epilogue's exchange slots
     // Workgroup -> (network, step, tile group).  A workgroup streams its network's whole transformed filter bank (2.95 MB per
@@ -339,15 +340,16 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
         return (pix00 >= 0 && ty + dy < g.H && tx + dx < g.W) ? pix00 + dy * (g.W + 2) + dx : -1;
     };
 
-    if (net == 0) {
+    if (net == 0 || raw_both) {
         // fAffine: raw sums of this wave's 32 channels, finished by conv1_finish_kernel once z1 of the step exists
+        // (raw_both: the training path takes fFeatures' raw sums too, in channels [64, 128) of the slab)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int64_t op = out_pix(2 * bi + dy, 2 * bj + dx);
                 if (op < 0) continue;
-                float* dst = h2P + op * IFL_H2 + mh * 32 + 4 * h;
+                float* dst = h2P + op * IFL_H2 + net * IFL_HID + mh * 32 + 4 * h;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
                     *(f32x4*)(dst + gq * 8) = f32x4{Y[dy][dx][gq * 4], Y[dy][dx][gq * 4 + 1], Y[dy][dx][gq * 4 + 2], Y[dy][dx][gq * 4 + 3]};
@@ -391,7 +393,7 @@ int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipS
 }
 
 int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
-                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st)
+                         int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st, int raw_both)
 {
     if (nsteps <= 0) return 0;
     const IflXGeom g = ifl_xgeom(B, H, W);
@@ -401,8 +403,8 @@ int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, 
         return IFL_ENOTSUP;
     }
     dim3 grid(ngroups * ncombo), block(512);
-    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino4_kernel<1>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
-    else hipLaunchKernelGGL(conv1_ft_wino4_kernel<2>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo);
+    if (level == 1) hipLaunchKernelGGL(conv1_ft_wino4_kernel<1>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo, raw_both);
+    else hipLaunchKernelGGL(conv1_ft_wino4_kernel<2>, grid, block, 0, st, vg, h2all, h2_step_stride, params, steps, off, g, ngroups, ncombo, raw_both);
     IFL_LAUNCH_CHECK();
     return 0;
 }

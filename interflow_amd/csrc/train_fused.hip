@@ -21,9 +21,14 @@
 #include "ifl_common.h"
 #include "../../include/interflow_hip.h"
 
+int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream);
+int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
+                      int B, int h, int w, int C, hipStream_t stream);
 int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
                        float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, float* dbias_part, int B,
                        int h, int w, int C, hipStream_t stream);
+
+#define IFL_TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 namespace {
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256)
 void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
 {
     const ifl_pack_desc d = table[blockIdx.y];
-    const int cin_real = d.real0 + d.real1, cin_pad = d.pad0 + d.pad1;
+    const int cin_real = d.cin_src ? d.cin_src : d.real0 + d.real1, cin_pad = d.pad0 + d.pad1;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < d.nelem; idx += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         if (d.mode == IFL_PACK_FWD || d.mode == IFL_PACK_TRANSPOSED) {
@@ -160,9 +165,28 @@ void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
             }
         } else if (d.mode == IFL_PACK_VECTOR) {
             if (idx < d.cout_real) v = d.src[idx];
+        } else if (d.mode == IFL_PACK_WINO4) {
+            // [mh][bi][bj][s][il][jl][hh][o][e]: position (3 bi + il, 3 bj + jl), output mh*32 + o, input s*8 + hh*4 + e
+            const int e = idx & 3, o = (idx >> 2) & 31, hh = (idx >> 7) & 1;
+            int r = (int)(idx >> 8);
+            const int jl = r % 3; r /= 3;
+            const int il = r % 3; r /= 3;
+            const int sc = r % 40; r /= 40;
+            const int bj = r & 1, bi = (r >> 1) & 1, mh = r >> 2;
+            const int co = mh * 32 + o, ci = d.real0 + sc * 8 + hh * 4 + e;
+            const int pi = 3 * bi + il, pj = 3 * bj + jl;
+            const float* g = d.src + ((int64_t)co * cin_real + ci) * 9;
+            const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double u = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) u += G[pi][a] * (double)g[a * 3 + b] * G[pj][b];
+            v = (float)u;
         } else {                              // IFL_PACK_GRAD: dense [cout_pad][cin_pad][taps] -> the parameter's [cout][cin][taps]
             const int tap = idx % d.taps; int64_t r = idx / d.taps;
-            const int ci = r % cin_real, co = r / cin_real;
+            const int ci = r % (d.real0 + d.real1), co = r / (d.real0 + d.real1);
             const int col = ci < d.real0 ? ci : d.pad0 + (ci - d.real0);
             v = d.src[((int64_t)co * cin_pad + col) * d.taps + tap];
         }
@@ -208,7 +232,6 @@ int conv(const float* s0, int c0, const float* s1, int c1, const float* w, const
     return ifl_conv2d(&d, B, h, w_, st);
 }
 
-#define IFL_TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 int check_level(const ifl_train_level* L) {
     IFL_CHECK_ARG(L && L->steps && L->nsteps >= 1, IFL_EINVAL, "train level: no steps");
@@ -227,12 +250,16 @@ int check_level(const ifl_train_level* L) {
                           N.an1_part && N.an2_part && N.dlogs_part && N.dbias_part && N.ldpart && N.bias3 && N.logs3 &&
                           N.an1_bias && N.an1_logs && N.an2_bias && N.an2_logs && L->dh[i] && (!N.has_z1 || N.w1t),
                           IFL_EINVAL, "train step %d net %d: null pointer", s, i);
+            IFL_CHECK_ARG(N.p1_stride == 64 || (N.p1_stride == 128 && L->raw && !N.has_z1), IFL_EINVAL, "train step %d net %d: p1 stride %d", s, i, N.p1_stride);
             IFL_CHECK_ARG(N.n >= 1 && N.c0 >= 0 && N.c0 + N.n <= L->C && N.hstride % 32 == 0 && 2 * N.n <= N.hstride && N.hstride <= 96,
                           IFL_EINVAL, "train step %d net %d: channels [%d, %d) of %d, %d rows", s, i, N.c0, N.c0 + N.n, L->C, N.hstride);
         }
     }
     return 0;
 }
+
+static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 224 && sizeof(ifl_train_step) == 512 && sizeof(ifl_train_level) == 152,
+              "the Python side (train_fused.py) mirrors these structs");
 
 }  // namespace
 
@@ -248,16 +275,41 @@ extern "C" int ifl_pack_table(const ifl_pack_desc* table_dev, int n, int64_t max
 
 extern "C" int64_t ifl_affine_px_blocks(int64_t npx) { return (npx + APX - 1) / APX; }
 
+extern "C" int64_t ifl_train_vg_floats(int B, int h, int w) { return ifl_vg_floats(B, h, w); }
+
+extern "C" int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float* wx, int64_t wx_step, int nsteps, float* raw,
+                                    int64_t raw_step, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(ft_ring && vg && wx && raw && nsteps >= 1 && B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "train bulk conv1: null pointer / shape");
+    IFL_CHECK_ARG(wx_step >= 2 * (int64_t)36 * IFL_HID * IFL_FT && raw_step >= (int64_t)B * (h + 2) * (w + 2) * IFL_H2, IFL_EINVAL, "train bulk conv1: strides");
+    hipStream_t st = (hipStream_t)stream;
+    IFL_TRY(ifl_k_wino4_input(ft_ring, vg, B, h, w, st));
+    IflStepOff off{};
+    off.w1x[0] = 0;
+    off.w1x[1] = (int64_t)36 * IFL_HID * IFL_FT;
+    // launches of 4 steps (8 (network, step) pairs: one per XCD) on large planes, 8 on small ones, as the inference schedule
+    const int per = (int64_t)B * h * w >= 100000 ? 4 : 8;
+    for (int s0 = 0; s0 < nsteps; s0 += per) {
+        const int n = nsteps - s0 < per ? nsteps - s0 : per;
+        IflStepList steps{};
+        for (int i = 0; i < n; ++i) steps.off[i] = (int64_t)(s0 + i) * wx_step;
+        IFL_TRY(ifl_k_conv1_ft_wino4(vg, raw + (int64_t)s0 * raw_step, raw_step, wx, steps, n, off, B, h, w, h >= 64 ? 1 : 2, st, 1));
+    }
+    return 0;
+}
+
 extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
 {
     IFL_TRY(check_level(L));
     hipStream_t st = (hipStream_t)stream;
     const int B = L->B, h = L->h, w = L->w, C = L->C;
     const int64_t npx = (int64_t)B * h * w;
+    int cstep = -1;                           // index among the conditional steps (the bulk slab's)
     for (int s = 0; s < L->nsteps; ++s) {
         const ifl_train_step& S = L->steps[s];
         IFL_TRY(affine_fwd(S.z_in, S.z_a, S.M, S.c, npx, C, st));
         if (!S.cond) continue;
+        ++cstep;
         for (int i = 0; i < 2; ++i) {
             const ifl_train_net& N = S.net[i];
             const float* zsrc = i == 0 ? S.z_a : S.z_mid;
@@ -265,11 +317,19 @@ extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
             if (N.has_z1) {
                 hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
                 IFL_LAUNCH_CHECK();
-                IFL_TRY(conv(L->z1ring, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
-            } else {
+                if (L->raw) {                 // z1's taps here, the conditioning part from the bulk slab
+                    ifl_conv_desc d = {};
+                    d.src[0] = L->z1ring; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
+                    d.w = N.w1; d.out = N.p1; d.out_stride = 64; d.cout = 64; d.taps = 9;
+                    d.res1 = L->raw + (int64_t)cstep * L->raw_step; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
+                    IFL_TRY(ifl_conv2d(&d, B, h, w, st));
+                } else {
+                    IFL_TRY(conv(L->z1ring, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+                }
+            } else if (!L->raw) {
                 IFL_TRY(conv(L->ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
             }
-            IFL_TRY(ifl_an_relu_fwd(N.p1, N.a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
+            IFL_TRY(ifl_k_an_relu_fwd(N.p1, N.p1_stride, N.a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
             IFL_TRY(conv(N.a1, 64, nullptr, 0, N.w2, nullptr, N.p2, 64, 1, B, h, w, st));
             IFL_TRY(ifl_an_relu_fwd(N.p2, N.a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
             IFL_TRY(conv(N.a2, 64, nullptr, 0, N.w3, N.bias3, N.hraw, N.hstride, 9, B, h, w, st));
@@ -306,7 +366,7 @@ extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out
                 // 1x1: a1 -> p2
                 IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
                 IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
-                IFL_TRY(ifl_an_relu_bwd(N.p1, da, dp, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
+                IFL_TRY(ifl_k_an_relu_bwd(N.p1, N.p1_stride, da, dp, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
                 // first 3x3: (z1 | ft) -> p1
                 if (N.has_z1) {
                     const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);

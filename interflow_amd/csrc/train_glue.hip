@@ -24,9 +24,9 @@ __device__ __forceinline__ int64_t ring_px(int64_t p, int h, int w) {
     return (b * (h + 2) + y + 1) * (w + 2) + x + 1;
 }
 
-// x, y ringed [B][h+2][w+2][C], C = 64: thread = (pixel lane, channel quad)
+// x, y ringed [B][h+2][w+2][C], C = 64 (x may be a 64-channel range of a wider buffer: pixel stride xs): thread = (pixel lane, channel quad)
 __global__ __launch_bounds__(256)
-void an_relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ bias,
+void an_relu_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__ y, const float* __restrict__ bias,
                         const float* __restrict__ logs, int64_t npx, int h, int w, int C)
 {
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -35,8 +35,8 @@ void an_relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = expf(s[e]);
     for (int64_t p = (int64_t)blockIdx.x * GPX + pl; p < npx && p < (int64_t)(blockIdx.x + 1) * GPX; p += 16) {
-        const int64_t o = ring_px(p, h, w) * C + cq * 4;
-        f32x4 v = *(const f32x4*)(x + o);
+        const int64_t rp = ring_px(p, h, w), o = rp * C + cq * 4;
+        f32x4 v = *(const f32x4*)(x + rp * xs + cq * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { float u = (v[e] + b[e]) * s[e]; v[e] = u > 0.f ? u : 0.f; }
         *(f32x4*)(y + o) = v;
@@ -45,7 +45,7 @@ void an_relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, cons
 
 // dx = dy * [u > 0] * s;  part[block][0:C] = sum dx (= d bias),  part[block][C:2C] = sum dy [u > 0] u (= d logs)
 __global__ __launch_bounds__(256)
-void an_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+void an_relu_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, float* __restrict__ dx,
                         const float* __restrict__ bias, const float* __restrict__ logs, float* __restrict__ part,
                         int64_t npx, int h, int w, int C)
 {
@@ -57,8 +57,8 @@ void an_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ d
     for (int e = 0; e < 4; ++e) s[e] = expf(s[e]);
     f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sl = sb;
     for (int64_t p = (int64_t)blockIdx.x * GPX + pl; p < npx && p < (int64_t)(blockIdx.x + 1) * GPX; p += 16) {
-        const int64_t o = ring_px(p, h, w) * C + cq * 4;
-        const f32x4 v = *(const f32x4*)(x + o), g = *(const f32x4*)(dy + o);
+        const int64_t rp = ring_px(p, h, w), o = rp * C + cq * 4;
+        const f32x4 v = *(const f32x4*)(x + rp * xs + cq * 4), g = *(const f32x4*)(dy + o);
         f32x4 d;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -186,13 +186,31 @@ void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ 
 
 extern "C" int64_t ifl_an_relu_blocks(int B, int h, int w) { return ((int64_t)B * h * w + GPX - 1) / GPX; }
 
-extern "C" int ifl_an_relu_fwd(const float* x, float* y, const float* bias, const float* logs, int B, int h, int w, int C, void* stream)
+int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream)
 {
-    IFL_CHECK_ARG(x && y && bias && logs, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(x && y && bias && logs && xs >= C && xs % 4 == 0, IFL_EINVAL, "null pointer / stride");
     IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
     IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
     const int64_t npx = (int64_t)B * h * w;
-    hipLaunchKernelGGL(an_relu_fwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, (hipStream_t)stream, x, y, bias, logs, npx, h, w, C);
+    hipLaunchKernelGGL(an_relu_fwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, stream, x, xs, y, bias, logs, npx, h, w, C);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_an_relu_fwd(const float* x, float* y, const float* bias, const float* logs, int B, int h, int w, int C, void* stream)
+{
+    return ifl_k_an_relu_fwd(x, C, y, bias, logs, B, h, w, C, (hipStream_t)stream);
+}
+
+int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
+                      int B, int h, int w, int C, hipStream_t stream)
+{
+    IFL_CHECK_ARG(x && dy && dx && bias && logs && partials && xs >= C && xs % 4 == 0, IFL_EINVAL, "null pointer / stride");
+    IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
+    const int64_t npx = (int64_t)B * h * w;
+    hipLaunchKernelGGL(an_relu_bwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, stream, x, xs, dy, dx, bias, logs,
+                       partials, npx, h, w, C);
     IFL_LAUNCH_CHECK();
     return 0;
 }
@@ -200,14 +218,7 @@ extern "C" int ifl_an_relu_fwd(const float* x, float* y, const float* bias, cons
 extern "C" int ifl_an_relu_bwd(const float* x, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
                                int B, int h, int w, int C, void* stream)
 {
-    IFL_CHECK_ARG(x && dy && dx && bias && logs && partials, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
-    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
-    const int64_t npx = (int64_t)B * h * w;
-    hipLaunchKernelGGL(an_relu_bwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, bias, logs,
-                       partials, npx, h, w, C);
-    IFL_LAUNCH_CHECK();
-    return 0;
+    return ifl_k_an_relu_bwd(x, C, dy, dx, bias, logs, partials, B, h, w, C, (hipStream_t)stream);
 }
 
 extern "C" int ifl_coupling_blocks(int h, int w) { return (h * w + CPX - 1) / CPX; }

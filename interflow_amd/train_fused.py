@@ -54,7 +54,7 @@ class IflTrainNet(Structure):
     _fields_ = [(k, c_void_p) for k in ("w1", "w2", "w3", "w1t", "w2t", "w3t", "an1_bias", "an1_logs", "an2_bias", "an2_logs",
                                         "bias3", "logs3", "p1", "a1", "p2", "a2", "hraw", "dW1", "dW2", "dW3", "an1_part",
                                         "an2_part", "dlogs_part", "dbias_part", "ldpart")] + \
-               [(k, c_int32) for k in ("c0", "n", "hstride", "has_z1")]
+               [(k, c_int32) for k in ("c0", "n", "hstride", "has_z1", "p1_stride", "pad_")]
 
 
 class IflTrainStep(Structure):
@@ -65,14 +65,23 @@ class IflTrainStep(Structure):
 class IflTrainLevel(Structure):
     _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch")] + \
                [("eps", c_float), ("pad_", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
-                ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep))]
+                ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
+                ("raw", c_void_p), ("raw_step", c_int64)]
+
+
+assert ctypes.sizeof(IflTrainNet) == 224 and ctypes.sizeof(IflTrainStep) == 512 and ctypes.sizeof(IflTrainLevel) == 152
 
 
 PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode", "<i4"), ("cout_real", "<i4"),
                        ("cout_pad", "<i4"), ("taps", "<i4"), ("real0", "<i4"), ("pad0", "<i4"), ("real1", "<i4"),
-                       ("pad1", "<i4"), ("a0", "<i4"), ("acnt", "<i4")])
-assert PACK_DTYPE.itemsize == 64
-PACK_FWD, PACK_TRANSPOSED, PACK_VECTOR, PACK_GRAD = 0, 1, 2, 3
+                       ("pad1", "<i4"), ("a0", "<i4"), ("acnt", "<i4"), ("cin_src", "<i4"), ("pad_", "<i4")])
+assert PACK_DTYPE.itemsize == 72
+PACK_FWD, PACK_TRANSPOSED, PACK_VECTOR, PACK_GRAD, PACK_WINO4 = 0, 1, 2, 3, 4
+WX_FLOATS = 36 * 64 * N_RRDB_CH          # one network's first-convolution weights in the 6x6 Winograd domain
+
+# The conditioning part of the first convolutions through the Winograd bulk kernel of the inference path (ifl_train_bulk_conv1)
+# instead of 32 direct convolutions per level; tests switch it off to compare.
+USE_BULK = True
 
 _bound = False
 
@@ -89,6 +98,11 @@ def _lib():
         L.ifl_train_level_fwd.restype = ctypes.c_int
         L.ifl_train_level_bwd.argtypes = [POINTER(IflTrainLevel), c_void_p, c_void_p, c_void_p, c_void_p]
         L.ifl_train_level_bwd.restype = ctypes.c_int
+        L.ifl_train_vg_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.ifl_train_vg_floats.restype = c_int64
+        L.ifl_train_bulk_conv1.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_int, c_void_p, c_int64, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, c_void_p]
+        L.ifl_train_bulk_conv1.restype = ctypes.c_int
         _bound = True
     return L
 
@@ -102,10 +116,11 @@ def _net_params(seq):
 class LevelPlan:
     """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
 
-    def __init__(self, steps, B, h, w, C, device):
+    def __init__(self, steps, B, h, w, C, device, bulk=True):
         L = _lib()
         self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
         self.busy = False
+        self.bulk = bool(bulk)
         ns = len(self.steps)
         self.cond = [hasattr(s, "affine") for s in self.steps]
         nc = sum(self.cond)
@@ -139,12 +154,19 @@ class LevelPlan:
         sizes_w, sizes_g, sizes_r = [], [], []
         for i, (_, _, n, z1) in enumerate(self.nets):
             hs = self.hstride[i]
-            sizes_w.append([64 * cin1[i] * 9, 64 * 64, hs * 64 * 9, (32 * 64 * 9) if z1 else 0, 64 * 64, 64 * hs * 9, hs])
+            w1_fwd = (64 * 32 * 9 if z1 else 0) if self.bulk else 64 * cin1[i] * 9        # bulk: only z1's taps run as a direct conv
+            sizes_w.append([w1_fwd, 64 * 64, hs * 64 * 9, (32 * 64 * 9) if z1 else 0, 64 * 64, 64 * hs * 9, hs])
             sizes_g.append([64 * cin1[i] * 9, 64 * 64, hs * 64 * 9])
             cin_real = (ch if z1 else 0) + N_RRDB_CH
             sizes_r.append([64 * cin_real * 9, 64 * 64, 2 * n * 64 * 9])
         per_w, per_g, per_r = (sum(sum(x) for x in s) for s in (sizes_w, sizes_g, sizes_r))
         self.wbuf, self.dW, self.graw = zeros(max(nc, 1) * per_w), zeros(max(nc, 1) * per_g), zeros(max(nc, 1) * per_r)
+        if self.bulk and nc:
+            self.vg = zeros(int(L.ifl_train_vg_floats(B, h, w)))
+            self.wx = zeros(nc * 2 * WX_FLOATS + 4096)                   # + slack: the kernel's weight ring reads past the last block
+            self.raw = zeros(nc, B, h + 2, w + 2, 128)
+        else:
+            self.bulk = False
         # ---- scratch ----
         self.z1ring, self.dz1ring = zeros(B, h + 2, w + 2, 32), zeros(B, h + 2, w + 2, 32)
         self.dzs = zeros(4, B, h, w, C)
@@ -185,12 +207,16 @@ class LevelPlan:
                 offs = np.cumsum([0] + sizes_w[i])
                 wv = [self.wbuf[wo + offs[k]: wo + offs[k + 1]] for k in range(7)]
                 wo += int(offs[-1])
-                N.w1, N.w2, N.w3 = ptr(wv[0]), ptr(wv[1]), ptr(wv[2])
+                N.w1 = ptr(wv[0]) if wv[0].numel() else ptr(self.wx)          # (unused for a network whose whole first conv is bulk)
+                N.w2, N.w3 = ptr(wv[1]), ptr(wv[2])
                 N.w1t = ptr(wv[3]) if z1 else None
                 N.w2t, N.w3t, N.bias3 = ptr(wv[4]), ptr(wv[5]), ptr(wv[6])
                 N.an1_bias, N.an1_logs, N.an2_bias, N.an2_logs, N.logs3 = ptr(an1b), ptr(an1l), ptr(an2b), ptr(an2l), ptr(l3)
                 a = self.act[ci, i]
                 N.p1, N.a1, N.p2, N.a2 = ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3])
+                N.p1_stride = 64
+                if self.bulk and not z1:                                       # p1 = the network's 64 channels of the bulk slab
+                    N.p1, N.p1_stride = ptr(self.raw[ci]) + 64 * 4, 128
                 N.hraw = ptr(self.hraw[i][ci])
                 goffs = np.cumsum([0] + sizes_g[i])
                 gv = [self.dW[go + goffs[k]: go + goffs[k + 1]] for k in range(3)]
@@ -204,8 +230,16 @@ class LevelPlan:
                 common1 = dict(cout_real=64, cout_pad=64, taps=9, real0=r0, pad0=p0, real1=N_RRDB_CH, pad1=N_RRDB_CH)
                 common2 = dict(cout_real=64, cout_pad=64, taps=1, real0=64, pad0=64, real1=0, pad1=0)
                 common3 = dict(cout_real=2 * n, cout_pad=hs, taps=9, real0=64, pad0=64, real1=0, pad1=0)
-                pack_rows += [dict(src=ptr(w1), dst=ptr(wv[0]), nelem=wv[0].numel(), mode=PACK_FWD, **common1),
-                              dict(src=ptr(w2), dst=ptr(wv[1]), nelem=wv[1].numel(), mode=PACK_FWD, **common2),
+                if not self.bulk:
+                    pack_rows.append(dict(src=ptr(w1), dst=ptr(wv[0]), nelem=wv[0].numel(), mode=PACK_FWD, **common1))
+                else:
+                    if z1:
+                        pack_rows.append(dict(src=ptr(w1), dst=ptr(wv[0]), nelem=wv[0].numel(), mode=PACK_FWD, cout_real=64, cout_pad=64,
+                                              taps=9, real0=ch, pad0=32, real1=0, pad1=0, cin_src=ch + N_RRDB_CH))
+                    wxv = self.wx[(ci * 2 + i) * WX_FLOATS:(ci * 2 + i + 1) * WX_FLOATS]
+                    pack_rows.append(dict(src=ptr(w1), dst=ptr(wxv), nelem=WX_FLOATS, mode=PACK_WINO4, cout_real=64, cout_pad=64, taps=9,
+                                          real0=ch if z1 else 0, real1=N_RRDB_CH, cin_src=(ch if z1 else 0) + N_RRDB_CH))
+                pack_rows += [dict(src=ptr(w2), dst=ptr(wv[1]), nelem=wv[1].numel(), mode=PACK_FWD, **common2),
                               dict(src=ptr(w3), dst=ptr(wv[2]), nelem=wv[2].numel(), mode=PACK_FWD, **common3),
                               dict(src=ptr(w2), dst=ptr(wv[4]), nelem=wv[4].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=64, **common2),
                               dict(src=ptr(w3), dst=ptr(wv[5]), nelem=wv[5].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=64, **common3),
@@ -247,7 +281,10 @@ class LevelPlan:
             lv.dh[k] = ptr(self.dh[k])
             lv.d64[k] = ptr(self.d64[k])
         lv.steps = ctypes.cast(self.c_steps, POINTER(IflTrainStep))
+        if self.bulk:
+            lv.raw, lv.raw_step = ptr(self.raw), self.raw[0].numel()
         self.level = lv
+        self.nc = nc
 
     def matches(self, params):
         return len(params) == len(self.param_ptrs) and all(p.data_ptr() == q for p, q in zip(params, self.param_ptrs))
@@ -286,6 +323,10 @@ class _LevelFn(torch.autograd.Function):
             plan.c.copy_(c_all)
             plan.level.ft = ft_ring.data_ptr() if ft_ring is not None else None
             plan.run_table(plan.pack_tab)
+            if plan.bulk:
+                hip.check(L.ifl_train_bulk_conv1(hip._ptr(ft_ring), hip._ptr(plan.vg), hip._ptr(plan.wx), 2 * WX_FLOATS, plan.nc,
+                                                 hip._ptr(plan.raw), plan.raw[0].numel(), plan.B, plan.h, plan.w, hip._stream()),
+                          "ifl_train_bulk_conv1")
             hip.check(L.ifl_train_level_fwd(ctypes.byref(plan.level), hip._stream()), "ifl_train_level_fwd")
             ld = plan.ldpart.sum(dim=(0, 1, 3))
         return plan.z_last.clone(), ld
@@ -373,7 +414,7 @@ def usable(fu, feats) -> bool:
 
 def _plan_for(fu, level, steps, B, h, w, C, device, params):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device))
+    key = (level, B, h, w, C, str(device), USE_BULK)
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:
@@ -381,7 +422,7 @@ def _plan_for(fu, level, steps, B, h, w, C, device, params):
             return p
     if len(plans) >= MAX_PLANS_PER_SHAPE:
         return None
-    p = LevelPlan(steps, B, h, w, C, device)
+    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK)
     plans.append(p)
     return p
 

@@ -180,6 +180,16 @@ def test_fused_level_training_vs_oracle():
     assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
+    # the level drivers with every first convolution in the direct form (no Winograd bulk launch)
+    from interflow_amd import train_fused
+    train_fused.USE_BULK = False
+    try:
+        z4, nll4, ld4, _, loss4 = step()
+    finally:
+        train_fused.USE_BULK = True
+    assert rel(z4, z) < 1e-5 and rel(ld4, ld) < 1e-5 and rel(loss4, loss) < 1e-5
+    for k, g in fused.items():
+        assert rel(named[k].grad, g) < 2e-4, k
     # train_step's mode: the level functions add into existing .grad tensors themselves (one multi-tensor add per level)
     from interflow_amd.train_fused import accumulate_into_grad
     for p in named.values():
