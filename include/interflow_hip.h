@@ -288,6 +288,8 @@ typedef struct ifl_train_net {
     float *an1_part, *an2_part;                  /* [ifl_an_relu_blocks][128] partial sums (d bias | d logs)                     */
     float *dlogs_part, *dbias_part;              /* [B * ifl_coupling_blocks][2n] partial sums of d logs3 and of d bias3         */
     float *ldpart;                               /* [B][ifl_coupling_blocks] signed per-block sums of log scale                  */
+    float *dp1;                                  /* optional: the gradient wrt p1 is kept here (ringed, 64 channels, zero ring)
+                                                    instead of a scratch buffer, for a batched weight gradient afterwards        */
     int32_t c0, n, hstride, has_z1;              /* coupling on channels [c0, c0+n); has_z1: the network also reads z[:, :ch]    */
     int32_t p1_stride, pad_;                     /* pixel stride of p1 (64; 128 when p1 is a channel range of the bulk slab)     */
 } ifl_train_net;
@@ -304,7 +306,8 @@ typedef struct ifl_train_step {
 
 typedef struct ifl_train_level {
     int32_t B, h, w, C, ch, nsteps, branch, ft_ch;   /* ch = C/2 channels feed the networks; branch as ifl_coupling_fwd         */
-    float eps;  int32_t pad_;
+    float eps;  int32_t skip_ft_wgrad;           /* != 0: the backward leaves the first convolutions' weight gradient wrt ft
+                                                    to the caller (ifl_wino4_kmajor + GEMM + ifl_wino4_dw over the saved dp1)     */
     const float* ft;                             /* conditioning features, ringed, ft_ch channels (no gradient towards them)     */
     float *z1ring, *dz1ring;                     /* scratch, ringed 32 channels, zero outside the interior's first ch channels   */
     float *dz[4];                                /* scratch, [B][h][w][C]                                                        */
@@ -320,6 +323,19 @@ typedef struct ifl_train_level {
  * by the Winograd F(4x4,3x3) bulk kernel (the same kernel the inference path uses): raw[step][..][0:64] = fAffine's sums,
  * [64:128] = fFeatures'.  wx: per step two IFL_PACK_WINO4 blocks (fAffine, fFeatures), wx_step floats apart, plus 4096
  * floats of slack behind the last one.  vg: ifl_train_vg_floats(B, h, w) floats of scratch.                              */
+/* Weight gradient of those convolutions in the same Winograd domain (36 multiplications per 4x4 outputs instead of 144):
+ *   dU_p[row][ci] = sum_tiles dM_p[row][tile] * V_p[ci][tile]  for each of the 36 positions p,   dg = G^T dU G
+ * with V = B^T d B of the 6x6 windows of ft and dM = A dY A^T of the 4x4 blocks of the saved gradients (row = pair*64 +
+ * output channel).  ifl_wino4_kmajor writes either transform K-major, out[p][row0 + c][tile] (K = ifl_wino4_tiles() tiles
+ * per row; mode 0: src = ringed ft with C channels; mode 1: src = ringed gradient planes of C = 64 channels, n_planes of
+ * them plane_stride floats apart, rows n*64 + c); the 36 GEMMs C_p = dM_p V_p^T are plain batched GEMMs; ifl_wino4_dw
+ * maps dU [36][rows][320] back to 3x3 taps and writes them into each pair's parameter-layout gradient,
+ * dst[pair][(co*cin[pair] + zoff[pair] + ci)*9 + tap], from a device table of ifl_wino4_dst records.                     */
+typedef struct ifl_wino4_dst { float* dst; int32_t cin, zoff; } ifl_wino4_dst;
+int64_t ifl_wino4_tiles(int B, int h, int w);
+int ifl_wino4_kmajor(int mode, const float* src, int C, int n_planes, int64_t plane_stride, float* out, int64_t rows_total,
+                     int64_t row0, int B, int h, int w, void* stream);
+int ifl_wino4_dw(const float* dU, int64_t rows_total, const ifl_wino4_dst* table_dev, int n_pairs, void* stream);
 int64_t ifl_train_vg_floats(int B, int h, int w);
 int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float* wx, int64_t wx_step, int nsteps, float* raw,
                          int64_t raw_step, int B, int h, int w, void* stream);

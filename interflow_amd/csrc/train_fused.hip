@@ -194,6 +194,124 @@ void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
     }
 }
 
+
+// ---- Winograd F(4x4,3x3) weight gradient: K-major transforms and the map back to 3x3 taps --------------------------------
+// Thread = (tile, channel quad): block 256 = 64 consecutive tiles x 4 quads; grid (tile blocks, C / 16, planes).  Stores: for
+// a fixed (position, channel) the 64 tiles of a wave are 256 contiguous bytes of out[p][row][tile].
+template <int MODE>
+__global__ __launch_bounds__(256)
+void wino4_kmajor_kernel(const float* __restrict__ src, int C, int64_t plane_stride, float* __restrict__ out, int64_t rows_total,
+                         int64_t row0, IflXGeom g, int64_t K)
+{
+    const int tl = threadIdx.x & 63, q = (threadIdx.x >> 6) + 4 * blockIdx.y;
+    const int64_t tile = (int64_t)blockIdx.x * 64 + tl;
+    if (tile >= g.ntiles) return;
+    const int tpi = g.TH * g.TW, W2 = g.W + 2;
+    const int b = tile / tpi, r2 = tile - b * tpi;
+    const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
+    const float* sp = src + (int64_t)blockIdx.z * plane_stride + q * 4;
+    f32x4 T[6][6];
+    if (MODE == 0) {                          // V = B^T d B of the 6x6 window whose corner is ring pixel (4 tr, 4 tc)
+        const float* base = sp + ((int64_t)(b * (g.H + 2) + 4 * tr) * W2 + 4 * tc) * C;
+        f32x4 Tc[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const bool cin = 4 * tc + c <= g.W + 1;
+            f32x4 x[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                x[r] = (cin && 4 * tr + r <= g.H + 1) ? *(const f32x4*)(base + (int64_t)(r * W2 + c) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            Tc[0][c] = 4.f * x[0] - 5.f * x[2] + x[4];
+            Tc[1][c] = (x[4] - 4.f * x[2]) + (x[3] - 4.f * x[1]);
+            Tc[2][c] = (x[4] - 4.f * x[2]) - (x[3] - 4.f * x[1]);
+            Tc[3][c] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
+            Tc[4][c] = (x[4] - x[2]) - 2.f * (x[3] - x[1]);
+            Tc[5][c] = 4.f * x[1] - 5.f * x[3] + x[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4* x = Tc[i];
+            T[i][0] = 4.f * x[0] - 5.f * x[2] + x[4];
+            T[i][1] = (x[4] - 4.f * x[2]) + (x[3] - 4.f * x[1]);
+            T[i][2] = (x[4] - 4.f * x[2]) - (x[3] - 4.f * x[1]);
+            T[i][3] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
+            T[i][4] = (x[4] - x[2]) - 2.f * (x[3] - x[1]);
+            T[i][5] = 4.f * x[1] - 5.f * x[3] + x[5];
+        }
+    } else {                                  // dM = A dY A^T of the 4x4 block whose corner is image pixel (4 tr, 4 tc)
+        const float* base = sp + ((int64_t)(b * (g.H + 2) + 4 * tr + 1) * W2 + 4 * tc + 1) * C;
+        f32x4 Tc[6][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool cin = 4 * tc + c < g.W;
+            f32x4 y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                y[r] = (cin && 4 * tr + r < g.H) ? *(const f32x4*)(base + (int64_t)(r * W2 + c) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            Tc[0][c] = y[0];
+            Tc[1][c] = (y[0] + y[2]) + (y[1] + y[3]);
+            Tc[2][c] = (y[0] + y[2]) - (y[1] + y[3]);
+            Tc[3][c] = (y[0] + 4.f * y[2]) + (2.f * y[1] + 8.f * y[3]);
+            Tc[4][c] = (y[0] + 4.f * y[2]) - (2.f * y[1] + 8.f * y[3]);
+            Tc[5][c] = y[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4* y = Tc[i];
+            T[i][0] = y[0];
+            T[i][1] = (y[0] + y[2]) + (y[1] + y[3]);
+            T[i][2] = (y[0] + y[2]) - (y[1] + y[3]);
+            T[i][3] = (y[0] + 4.f * y[2]) + (2.f * y[1] + 8.f * y[3]);
+            T[i][4] = (y[0] + 4.f * y[2]) - (2.f * y[1] + 8.f * y[3]);
+            T[i][5] = y[3];
+        }
+    }
+    const int64_t row = row0 + (int64_t)blockIdx.z * C + q * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int jc = 0; jc < 6; ++jc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[((int64_t)(i * 6 + jc) * rows_total + row + e) * K + tile] = T[i][jc][e];
+}
+
+// thread = (row, ci): dg = G^T dU G of the 36 values dU[p][row][ci]; pair = row / 64
+__global__ __launch_bounds__(256)
+void wino4_dw_kernel(const float* __restrict__ dU, int64_t rows_total, const ifl_wino4_dst* __restrict__ table)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows_total * IFL_FT) return;
+    const int64_t row = idx / IFL_FT; const int ci = idx - row * IFL_FT;
+    const ifl_wino4_dst d = table[row >> 6];
+    const int co = row & 63;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float t[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[a][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float u = dU[((int64_t)(i * 6 + j) * rows_total + row) * IFL_FT + ci];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) t[a][j] += G[i][a] * u;
+        }
+    float* dst = d.dst + ((int64_t)co * d.cin + d.zoff + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v += t[a][j] * G[j][b];
+            dst[a * 3 + b] = v;
+        }
+}
+
 template <int C>
 int launch_affine_fwd(const float* z, float* zo, const float* M, const float* c, int64_t npx, hipStream_t st) {
     hipLaunchKernelGGL(affine_px_fwd_kernel<C>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, z, zo, M, c, npx);
@@ -250,6 +368,7 @@ int check_level(const ifl_train_level* L) {
                           N.an1_part && N.an2_part && N.dlogs_part && N.dbias_part && N.ldpart && N.bias3 && N.logs3 &&
                           N.an1_bias && N.an1_logs && N.an2_bias && N.an2_logs && L->dh[i] && (!N.has_z1 || N.w1t),
                           IFL_EINVAL, "train step %d net %d: null pointer", s, i);
+            IFL_CHECK_ARG(!L->skip_ft_wgrad || N.dp1, IFL_EINVAL, "train step %d net %d: skip_ft_wgrad needs dp1", s, i);
             IFL_CHECK_ARG(N.p1_stride == 64 || (N.p1_stride == 128 && L->raw && !N.has_z1), IFL_EINVAL, "train step %d net %d: p1 stride %d", s, i, N.p1_stride);
             IFL_CHECK_ARG(N.n >= 1 && N.c0 >= 0 && N.c0 + N.n <= L->C && N.hstride % 32 == 0 && 2 * N.n <= N.hstride && N.hstride <= 96,
                           IFL_EINVAL, "train step %d net %d: channels [%d, %d) of %d, %d rows", s, i, N.c0, N.c0 + N.n, L->C, N.hstride);
@@ -258,7 +377,7 @@ int check_level(const ifl_train_level* L) {
     return 0;
 }
 
-static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 224 && sizeof(ifl_train_step) == 512 && sizeof(ifl_train_level) == 152,
+static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 232 && sizeof(ifl_train_step) == 528 && sizeof(ifl_train_level) == 152,
               "the Python side (train_fused.py) mirrors these structs");
 
 }  // namespace
@@ -276,6 +395,31 @@ extern "C" int ifl_pack_table(const ifl_pack_desc* table_dev, int n, int64_t max
 extern "C" int64_t ifl_affine_px_blocks(int64_t npx) { return (npx + APX - 1) / APX; }
 
 extern "C" int64_t ifl_train_vg_floats(int B, int h, int w) { return ifl_vg_floats(B, h, w); }
+
+extern "C" int64_t ifl_wino4_tiles(int B, int h, int w) { return ifl_xgeom(B, h, w).ntiles; }
+
+extern "C" int ifl_wino4_kmajor(int mode, const float* src, int C, int n_planes, int64_t plane_stride, float* out, int64_t rows_total,
+                                int64_t row0, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(src && out && (mode == 0 || mode == 1) && C % 16 == 0 && C >= 16 && n_planes >= 1 && n_planes <= 65535, IFL_EINVAL,
+                  "wino4 transform: mode %d, %d channels, %d planes", mode, C, n_planes);
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && row0 >= 0 && row0 + (int64_t)n_planes * C <= rows_total, IFL_EINVAL, "wino4 transform: rows");
+    const IflXGeom g = ifl_xgeom(B, h, w);
+    dim3 grid((g.ntiles + 63) / 64, C / 16, n_planes), block(256);
+    if (mode == 0) hipLaunchKernelGGL(wino4_kmajor_kernel<0>, grid, block, 0, (hipStream_t)stream, src, C, plane_stride, out, rows_total, row0, g, (int64_t)g.ntiles);
+    else hipLaunchKernelGGL(wino4_kmajor_kernel<1>, grid, block, 0, (hipStream_t)stream, src, C, plane_stride, out, rows_total, row0, g, (int64_t)g.ntiles);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_wino4_dw(const float* dU, int64_t rows_total, const ifl_wino4_dst* table_dev, int n_pairs, void* stream)
+{
+    IFL_CHECK_ARG(dU && table_dev && n_pairs >= 1 && rows_total == (int64_t)n_pairs * 64, IFL_EINVAL, "wino4 dw: %d pairs", n_pairs);
+    const int64_t n = rows_total * IFL_FT;
+    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dU, rows_total, table_dev);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float* wx, int64_t wx_step, int nsteps, float* raw,
                                     int64_t raw_step, int B, int h, int w, void* stream)
@@ -357,6 +501,7 @@ extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out
                 float* dh = L->dh[i];
                 float* da = L->d64[0];
                 float* dp = L->d64[1];
+                float* dp1 = N.dp1 ? N.dp1 : dp;        // gradient wrt the first convolution's output
                 IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part,
                                            N.dbias_part, B, h, w, C, st));
                 // Conv2dZeros 3x3: a2 -> hraw
@@ -366,19 +511,20 @@ extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out
                 // 1x1: a1 -> p2
                 IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
                 IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
-                IFL_TRY(ifl_k_an_relu_bwd(N.p1, N.p1_stride, da, dp, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
+                IFL_TRY(ifl_k_an_relu_bwd(N.p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
                 // first 3x3: (z1 | ft) -> p1
                 if (N.has_z1) {
                     const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
                     hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
                     IFL_LAUNCH_CHECK();
-                    IFL_TRY(ifl_conv2d_wgrad(L->z1ring, 32, 0, 32, dp, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
-                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
-                    IFL_TRY(conv(dp, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring, 32, 9, B, h, w, st));
+                    IFL_TRY(ifl_conv2d_wgrad(L->z1ring, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
+                    if (!L->skip_ft_wgrad)
+                        IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
+                    IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring, 32, 9, B, h, w, st));
                     hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring, dzn, npx, h, w, C, L->ch);
                     IFL_LAUNCH_CHECK();
-                } else {
-                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
+                } else if (!L->skip_ft_wgrad) {
+                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
                 }
                 g = dzn;
             }

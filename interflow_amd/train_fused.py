@@ -53,7 +53,7 @@ class accumulate_into_grad:
 class IflTrainNet(Structure):
     _fields_ = [(k, c_void_p) for k in ("w1", "w2", "w3", "w1t", "w2t", "w3t", "an1_bias", "an1_logs", "an2_bias", "an2_logs",
                                         "bias3", "logs3", "p1", "a1", "p2", "a2", "hraw", "dW1", "dW2", "dW3", "an1_part",
-                                        "an2_part", "dlogs_part", "dbias_part", "ldpart")] + \
+                                        "an2_part", "dlogs_part", "dbias_part", "ldpart", "dp1")] + \
                [(k, c_int32) for k in ("c0", "n", "hstride", "has_z1", "p1_stride", "pad_")]
 
 
@@ -64,12 +64,12 @@ class IflTrainStep(Structure):
 
 class IflTrainLevel(Structure):
     _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch")] + \
-               [("eps", c_float), ("pad_", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
+               [("eps", c_float), ("skip_ft_wgrad", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
                 ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
                 ("raw", c_void_p), ("raw_step", c_int64)]
 
 
-assert ctypes.sizeof(IflTrainNet) == 224 and ctypes.sizeof(IflTrainStep) == 512 and ctypes.sizeof(IflTrainLevel) == 152
+assert ctypes.sizeof(IflTrainNet) == 232 and ctypes.sizeof(IflTrainStep) == 528 and ctypes.sizeof(IflTrainLevel) == 152
 
 
 PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode", "<i4"), ("cout_real", "<i4"),
@@ -82,6 +82,11 @@ WX_FLOATS = 36 * 64 * N_RRDB_CH          # one network's first-convolution weigh
 # The conditioning part of the first convolutions through the Winograd bulk kernel of the inference path (ifl_train_bulk_conv1)
 # instead of 32 direct convolutions per level; tests switch it off to compare.
 USE_BULK = True
+# ... and their weight gradient wrt those 320 channels in the same Winograd domain (with USE_BULK): K-major transforms of ft
+# and of the saved output gradients, 36 plain GEMMs over the tiles (torch.bmm = rocBLAS), map back to 3x3 taps
+# (ifl_wino4_kmajor / ifl_wino4_dw): 4x fewer multiplications than the direct weight-gradient kernel.
+WINO_WGRAD = True
+WDST_DTYPE = np.dtype([("dst", "<u8"), ("cin", "<i4"), ("zoff", "<i4")])
 
 _bound = False
 
@@ -103,6 +108,13 @@ def _lib():
         L.ifl_train_bulk_conv1.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_int, c_void_p, c_int64, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_void_p]
         L.ifl_train_bulk_conv1.restype = ctypes.c_int
+        L.ifl_wino4_tiles.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.ifl_wino4_tiles.restype = c_int64
+        L.ifl_wino4_kmajor.argtypes = [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, c_int64, c_void_p, c_int64, c_int64,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p]
+        L.ifl_wino4_kmajor.restype = ctypes.c_int
+        L.ifl_wino4_dw.argtypes = [c_void_p, c_int64, c_void_p, ctypes.c_int, c_void_p]
+        L.ifl_wino4_dw.restype = ctypes.c_int
         _bound = True
     return L
 
@@ -116,7 +128,7 @@ def _net_params(seq):
 class LevelPlan:
     """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
 
-    def __init__(self, steps, B, h, w, C, device, bulk=True):
+    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True):
         L = _lib()
         self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
         self.busy = False
@@ -167,6 +179,13 @@ class LevelPlan:
             self.raw = zeros(nc, B, h + 2, w + 2, 128)
         else:
             self.bulk = False
+        self.wino_wgrad = bool(wino_wgrad) and self.bulk
+        if self.wino_wgrad:
+            K = int(L.ifl_wino4_tiles(B, h, w))
+            self.dp1 = zeros(nc * 2, B, h + 2, w + 2, 64)                # gradient wrt p1 of every (step, network), zero rings
+            self.Vt = zeros(36, N_RRDB_CH, K)
+            self.dM = zeros(36, nc * 2 * 64, K)
+            self.dU = zeros(36, nc * 2 * 64, N_RRDB_CH)
         # ---- scratch ----
         self.z1ring, self.dz1ring = zeros(B, h + 2, w + 2, 32), zeros(B, h + 2, w + 2, 32)
         self.dzs = zeros(4, B, h, w, C)
@@ -177,7 +196,7 @@ class LevelPlan:
 
         # ---- descriptors ----
         self.c_steps = (IflTrainStep * ns)()
-        pack_rows, grad_rows = [], []
+        pack_rows, grad_rows, wdst_rows = [], [], []
         self.param_slices = []                                          # per parameter of the function: how to find its gradient
         zi, ci = 0, 0
         wo = go = ro = 0
@@ -225,6 +244,8 @@ class LevelPlan:
                 N.an1_part, N.an2_part = ptr(self.an_part[ci, i, 0]), ptr(self.an_part[ci, i, 1])
                 N.dlogs_part, N.dbias_part = ptr(self.cpl_part[i][ci, 0]), ptr(self.cpl_part[i][ci, 1])
                 N.ldpart = ptr(self.ldpart[ci, i])
+                if self.wino_wgrad:
+                    N.dp1 = ptr(self.dp1[ci * 2 + i])
                 N.c0, N.n, N.hstride, N.has_z1 = c0, n, hs, 1 if z1 else 0
                 r0, p0 = (ch, 32) if z1 else (0, 0)
                 common1 = dict(cout_real=64, cout_pad=64, taps=9, real0=r0, pad0=p0, real1=N_RRDB_CH, pad1=N_RRDB_CH)
@@ -252,6 +273,7 @@ class LevelPlan:
                 grad_rows += [dict(src=ptr(gv[0]), dst=ptr(rv[0]), nelem=rv[0].numel(), mode=PACK_GRAD, **common1),
                               dict(src=ptr(gv[1]), dst=ptr(rv[1]), nelem=rv[1].numel(), mode=PACK_GRAD, **common2),
                               dict(src=ptr(gv[2]), dst=ptr(rv[2]), nelem=rv[2].numel(), mode=PACK_GRAD, **common3)]
+                wdst_rows.append((ptr(rv[0]), (ch if z1 else 0) + N_RRDB_CH, ch if z1 else 0))
                 self.param_slices += [("w", rv[0], w1.shape), ("an", (ci, i, 0, 0), an1b.shape), ("an", (ci, i, 0, 1), an1l.shape),
                                       ("w", rv[1], w2.shape), ("an", (ci, i, 1, 0), an2b.shape), ("an", (ci, i, 1, 1), an2l.shape),
                                       ("w", rv[2], w3.shape), ("cpl", (i, ci, 1), b3.shape), ("cpl", (i, ci, 0), l3.shape)]
@@ -283,6 +305,12 @@ class LevelPlan:
         lv.steps = ctypes.cast(self.c_steps, POINTER(IflTrainStep))
         if self.bulk:
             lv.raw, lv.raw_step = ptr(self.raw), self.raw[0].numel()
+        if self.wino_wgrad:
+            lv.skip_ft_wgrad = 1
+            arr = np.zeros(len(wdst_rows), dtype=WDST_DTYPE)
+            for k, r in enumerate(wdst_rows):
+                arr[k] = r
+            self.wdst = torch.from_numpy(arr.view(np.uint8)).to(device)
         self.level = lv
         self.nc = nc
 
@@ -346,6 +374,14 @@ class _LevelFn(torch.autograd.Function):
             hip.check(L.ifl_train_level_bwd(ctypes.byref(plan.level), hip._ptr(gz), hip._ptr(gld), hip._ptr(plan.dz_in), hip._stream()),
                       "ifl_train_level_bwd")
             plan.run_table(plan.grad_tab)
+            if plan.wino_wgrad:
+                rows = plan.dM.shape[1]
+                hip.check(L.ifl_wino4_kmajor(0, hip._ptr(ctx.ft_ring), N_RRDB_CH, 1, 0, hip._ptr(plan.Vt), N_RRDB_CH, 0,
+                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+                hip.check(L.ifl_wino4_kmajor(1, hip._ptr(plan.dp1), 64, plan.dp1.shape[0], plan.dp1[0].numel(), hip._ptr(plan.dM), rows, 0,
+                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+                torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
+                hip.check(L.ifl_wino4_dw(hip._ptr(plan.dU), rows, hip._ptr(plan.wdst), plan.dp1.shape[0], hip._stream()), "ifl_wino4_dw")
             C = plan.C
             dMc = plan.dM_part.sum(dim=1)                                  # [steps, C*C + C]
             an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
@@ -414,7 +450,7 @@ def usable(fu, feats) -> bool:
 
 def _plan_for(fu, level, steps, B, h, w, C, device, params):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device), USE_BULK)
+    key = (level, B, h, w, C, str(device), USE_BULK, WINO_WGRAD)
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:
@@ -422,7 +458,7 @@ def _plan_for(fu, level, steps, B, h, w, C, device, params):
             return p
     if len(plans) >= MAX_PLANS_PER_SHAPE:
         return None
-    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK)
+    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD)
     plans.append(p)
     return p
 

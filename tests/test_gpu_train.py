@@ -180,16 +180,18 @@ def test_fused_level_training_vs_oracle():
     assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
-    # the level drivers with every first convolution in the direct form (no Winograd bulk launch)
+    # the level drivers with every first convolution in the direct form (no Winograd bulk launch), and with the Winograd
+    # forward but the direct weight-gradient kernel
     from interflow_amd import train_fused
-    train_fused.USE_BULK = False
-    try:
-        z4, nll4, ld4, _, loss4 = step()
-    finally:
-        train_fused.USE_BULK = True
-    assert rel(z4, z) < 1e-5 and rel(ld4, ld) < 1e-5 and rel(loss4, loss) < 1e-5
-    for k, g in fused.items():
-        assert rel(named[k].grad, g) < 2e-4, k
+    for attr in ("USE_BULK", "WINO_WGRAD"):
+        setattr(train_fused, attr, False)
+        try:
+            z4, nll4, ld4, _, loss4 = step()
+        finally:
+            setattr(train_fused, attr, True)
+        assert rel(z4, z) < 1e-5 and rel(ld4, ld) < 1e-5 and rel(loss4, loss) < 1e-5
+        for k, g in fused.items():
+            assert rel(named[k].grad, g) < 2e-4, (attr, k)
     # train_step's mode: the level functions add into existing .grad tensors themselves (one multi-tensor add per level)
     from interflow_amd.train_fused import accumulate_into_grad
     for p in named.values():
@@ -202,6 +204,41 @@ def test_fused_level_training_vs_oracle():
     # a forward whose graph is dropped gives its arena back
     model(x.to(dev()), None, labels.to(dev()), lr_enc=fd, add_gt_noise=False)
     assert all(not p.busy for v in fu._train_plans.values() for p in v)
+
+
+def test_winograd_first_convolutions_at_patch_size():
+    """160x160 patches (80x80 and 40x40 planes, 800 and 200 tiles per image): the level drivers with the first convolutions'
+    conditioning part in the Winograd domain -- forward (bulk kernel) and weight gradient (K-major transforms + GEMM) --
+    against the same drivers with the direct kernels, which the small-size test above pins to the oracle."""
+    from interflow_amd import train_fused
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 2, 160
+    x = torch.from_numpy(synth.synth_images(91, B, H, H)).to(dev())
+    fd = {k: torch.from_numpy(v).to(dev()) for k, v in synth.synth_features(92, B, H, H).items()}
+    labels = torch.tensor([2, 4]).to(dev())
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    named = dict(model.named_parameters())
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        z, nll, ld, ll_ib = model(x, None, labels, lr_enc=fd, add_gt_noise=False)
+        (nll.mean() - ll_ib.mean()).backward()
+        return z.detach(), ld.detach(), {k: p.grad.clone() for k, p in named.items() if p.grad is not None}
+
+    z, ld, g = step()
+    train_fused.USE_BULK = False
+    try:
+        z0, ld0, g0 = step()
+    finally:
+        train_fused.USE_BULK = True
+    assert rel(z, z0) < 2e-5 and rel(ld, ld0) < 1e-5
+    worst = max(((k, rel(g[k], g0[k])) for k in g0), key=lambda t: t[1])
+    print(f"{len(g0)} gradients, worst {worst[0]}: {worst[1]:.2e}")
+    assert worst[1] < 2e-4, worst
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_decode_with_gradients_vs_oracle():
