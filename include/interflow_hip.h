@@ -225,6 +225,11 @@ typedef struct ifl_conv_desc {
 int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream);
 int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin, const float* dy, int dy_stride, int dy_off, int cout,
                      float* dW, int cin_total, int ci0, int taps, int B, int h, int w, void* stream);
+/* nz independent weight gradients of one shape in one launch (the same convolution of nz flow steps): problem k reads
+ * x + k*x_zstride, dy + k*dy_zstride and adds into dW + k*dw_zstride.                                                    */
+int ifl_conv2d_wgrad_batched(const float* x, int x_stride, int x_off, int cin, int64_t x_zstride, const float* dy, int dy_stride,
+                             int dy_off, int cout, int64_t dy_zstride, float* dW, int cin_total, int ci0, int64_t dw_zstride,
+                             int nz, int taps, int B, int h, int w, void* stream);
 
 /* ---- per-pixel operators of the coupling networks for the training path, forward and backward (train_glue.hip) ----
  * ifl_an_relu_*: y = relu((x + bias) * exp(logs)) on ringed channels-last planes [B][h+2][w+2][64] (flow.Conv2d's ActNorm,
@@ -290,6 +295,8 @@ typedef struct ifl_train_net {
     float *ldpart;                               /* [B][ifl_coupling_blocks] signed per-block sums of log scale                  */
     float *dp1;                                  /* optional: the gradient wrt p1 is kept here (ringed, 64 channels, zero ring)
                                                     instead of a scratch buffer, for a batched weight gradient afterwards        */
+    float *dp2, *dh;                             /* optional, likewise: the gradients wrt p2 (64 channels) and wrt hraw (hstride
+                                                    channels, zero outside the interior's rows [0, 2n))                          */
     int32_t c0, n, hstride, has_z1;              /* coupling on channels [c0, c0+n); has_z1: the network also reads z[:, :ch]    */
     int32_t p1_stride, pad_;                     /* pixel stride of p1 (64; 128 when p1 is a channel range of the bulk slab)     */
 } ifl_train_net;
@@ -300,12 +307,16 @@ typedef struct ifl_train_step {
     const float *M, *c;                          /* [C][C], [C]                                                                  */
     float *dM_part;                              /* [ifl_affine_px_blocks(B h w)][C*C + C] partial sums of dM (row-major) | dc   */
     float *z_in, *z_a, *z_mid, *z_out;           /* contiguous channels-last [B][h][w][C]; z_in is read, the others written      */
+    float *z1;                                   /* optional: this step's z1 plane (ringed, 32 channels, zero outside the interior's
+                                                    first ch channels), kept for the backward instead of the level's z1ring      */
     int32_t cond, pad_;
     ifl_train_net net[2];
 } ifl_train_step;
 
 typedef struct ifl_train_level {
     int32_t B, h, w, C, ch, nsteps, branch, ft_ch;   /* ch = C/2 channels feed the networks; branch as ifl_coupling_fwd         */
+    int32_t skip_step_wgrad, pad2_;              /* != 0: the backward leaves ALL weight gradients of the coupling networks to the
+                                                    caller (batched launches over the saved dp1 / dp2 / dh / z1 afterwards)       */
     float eps;  int32_t skip_ft_wgrad;           /* != 0: the backward leaves the first convolutions' weight gradient wrt ft
                                                     to the caller (ifl_wino4_kmajor + GEMM + ifl_wino4_dw over the saved dp1)     */
     const float* ft;                             /* conditioning features, ringed, ft_ch channels (no gradient towards them)     */

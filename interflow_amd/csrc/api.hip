@@ -781,6 +781,19 @@ extern "C" int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin
                        (hipStream_t)stream);
 }
 
+extern "C" int ifl_conv2d_wgrad_batched(const float* x, int x_stride, int x_off, int cin, int64_t x_zstride, const float* dy, int dy_stride,
+                                        int dy_off, int cout, int64_t dy_zstride, float* dW, int cin_total, int ci0, int64_t dw_zstride,
+                                        int nz, int taps, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(x && dy && dW, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape B=%d h=%d w=%d", B, h, w);
+    IFL_CHECK_ARG(ci0 >= 0 && (ci0 * 32 + cin) <= cin_total, IFL_EINVAL, "channel range outside dW");
+    IFL_CHECK_ARG(x_stride % 4 == 0 && x_off % 4 == 0 && dy_stride % 4 == 0 && dy_off % 4 == 0 && x_zstride % 4 == 0 && dy_zstride % 4 == 0,
+                  IFL_EINVAL, "strides and offsets must be multiples of 4 (16-byte loads)");
+    return ifl_k_wgrad(x, x_stride, x_off, cin, dy, dy_stride, dy_off, cout, dW, cin_total, ci0, taps, ifl_choose_geom(h, w), B,
+                       (hipStream_t)stream, nz, x_zstride, dy_zstride, dw_zstride);
+}
+
 extern "C" int ifl_quantize_u8_nhwc(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream)
 {
     IFL_CHECK_ARG(B >= 0 && C >= 1 && H >= 0 && W >= 0, IFL_EINVAL, "bad shape");

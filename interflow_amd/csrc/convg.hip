@@ -224,8 +224,13 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
 template <int CT, int TAPS>        // CT = cout / 32 (1..3)
 __global__ __launch_bounds__(256, 2)   // two workgroups per CU (74 KB of LDS each): without the bound CT = 2 takes 264 registers, one wave per SIMD
 void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __restrict__ DY, int dys, int dyoff,
-                  float* __restrict__ dW, int cin_total, int ci0, IflGeom g, int B)
+                  float* __restrict__ dW, int cin_total, int ci0, IflGeom g, int B, int64_t xz, int64_t dyz, int64_t dwz)
 {
+    // blockIdx.z: one of several independent problems of the same shape (the same convolution of different steps), their
+    // operands xz / dyz / dwz floats apart
+    X += (int64_t)blockIdx.z * xz;
+    DY += (int64_t)blockIdx.z * dyz;
+    dW += (int64_t)blockIdx.z * dwz;
     constexpr int NP = CT * TAPS, PPW = (NP + 3) / 4;            // pairs, pairs per wave
     constexpr int DS = CT * 32;                                   // dY row stride in LDS: the 32 lanes of a half-wave read consecutive words
     constexpr int XS = 32;
@@ -346,8 +351,9 @@ void wgrad_kernel(const float* __restrict__ X, int xs, int xoff, const float* __
 }
 
 int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,
-                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st)
+                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st, int nz, int64_t xz, int64_t dyz, int64_t dwz)
 {
+    IFL_CHECK_ARG(nz >= 1 && nz <= 65535, IFL_EINVAL, "wgrad: %d problems", nz);
     IFL_CHECK_ARG(cin % 32 == 0 && cin > 0 && cout % 32 == 0 && cout >= 32 && cout <= 96, IFL_ENOTSUP,
                   "wgrad: cin=%d cout=%d (cin a multiple of 32, cout 32, 64 or 96)", cin, cout);
     IFL_CHECK_ARG(taps == 9 || taps == 1, IFL_EINVAL, "wgrad: taps=%d", taps);
@@ -356,14 +362,15 @@ int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int 
     // beside an idle chip).  Each keeps its accumulators over its strided set of tiles and flushes them once with atomics,
     // 9 KB per 32x32 tile, so more workgroups also mean more atomic traffic.
     const int chunks = cin / 32;
-    int gx = 512 / chunks;
+    int gx = 512 / (chunks * nz);
+    if (nz > 1 && gx < 4) gx = 4;
 #ifdef IFL_EXP_GX
     if (getenv("IFL_EXP_GX")) gx = atoi(getenv("IFL_EXP_GX"));
 #endif
     if (gx < 16) gx = 16;
     if (gx > nwork) gx = nwork;
-    dim3 grid(gx, cin / 32), block(256);
-#define IFL_WG(CT, T) hipLaunchKernelGGL((wgrad_kernel<CT, T>), grid, block, 0, st, X, xs, xoff, DY, dys, dyoff, dW, cin_total, ci0, g, B)
+    dim3 grid(gx, cin / 32, nz), block(256);
+#define IFL_WG(CT, T) hipLaunchKernelGGL((wgrad_kernel<CT, T>), grid, block, 0, st, X, xs, xoff, DY, dys, dyoff, dW, cin_total, ci0, g, B, xz, dyz, dwz)
     const int ct = cout / 32;
     if (taps == 9) { if (ct == 1) IFL_WG(1, 9); else if (ct == 2) IFL_WG(2, 9); else IFL_WG(3, 9); }
     else { if (ct == 1) IFL_WG(1, 1); else if (ct == 2) IFL_WG(2, 1); else IFL_WG(3, 1); }

@@ -170,7 +170,8 @@ struct IflConvArgs {
 };
 int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
 int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,
-                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st);
+                int cin_total, int ci0, int taps, const IflGeom& g, int B, hipStream_t st, int nz = 1, int64_t xz = 0, int64_t dyz = 0,
+                int64_t dwz = 0);
 IflGeom ifl_choose_geom(int H, int W, int tpx = IFL_MT);
 
 int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out);     // base may be NULL (size query)

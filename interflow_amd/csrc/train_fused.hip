@@ -368,6 +368,8 @@ int check_level(const ifl_train_level* L) {
                           N.an1_part && N.an2_part && N.dlogs_part && N.dbias_part && N.ldpart && N.bias3 && N.logs3 &&
                           N.an1_bias && N.an1_logs && N.an2_bias && N.an2_logs && L->dh[i] && (!N.has_z1 || N.w1t),
                           IFL_EINVAL, "train step %d net %d: null pointer", s, i);
+            IFL_CHECK_ARG(!L->skip_step_wgrad || (N.dp1 && N.dp2 && N.dh && (!N.has_z1 || S.z1)), IFL_EINVAL,
+                          "train step %d net %d: skip_step_wgrad needs dp1, dp2, dh and z1", s, i);
             IFL_CHECK_ARG(!L->skip_ft_wgrad || N.dp1, IFL_EINVAL, "train step %d net %d: skip_ft_wgrad needs dp1", s, i);
             IFL_CHECK_ARG(N.p1_stride == 64 || (N.p1_stride == 128 && L->raw && !N.has_z1), IFL_EINVAL, "train step %d net %d: p1 stride %d", s, i, N.p1_stride);
             IFL_CHECK_ARG(N.n >= 1 && N.c0 >= 0 && N.c0 + N.n <= L->C && N.hstride % 32 == 0 && 2 * N.n <= N.hstride && N.hstride <= 96,
@@ -377,7 +379,7 @@ int check_level(const ifl_train_level* L) {
     return 0;
 }
 
-static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 232 && sizeof(ifl_train_step) == 528 && sizeof(ifl_train_level) == 152,
+static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 248 && sizeof(ifl_train_step) == 568 && sizeof(ifl_train_level) == 160,
               "the Python side (train_fused.py) mirrors these structs");
 
 }  // namespace
@@ -459,16 +461,17 @@ extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
             const float* zsrc = i == 0 ? S.z_a : S.z_mid;
             float* zdst = i == 0 ? S.z_mid : S.z_out;
             if (N.has_z1) {
-                hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
+                float* z1 = S.z1 ? S.z1 : L->z1ring;
+                hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, z1, npx, h, w, C, L->ch);
                 IFL_LAUNCH_CHECK();
                 if (L->raw) {                 // z1's taps here, the conditioning part from the bulk slab
                     ifl_conv_desc d = {};
-                    d.src[0] = L->z1ring; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
+                    d.src[0] = z1; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
                     d.w = N.w1; d.out = N.p1; d.out_stride = 64; d.cout = 64; d.taps = 9;
                     d.res1 = L->raw + (int64_t)cstep * L->raw_step; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
                     IFL_TRY(ifl_conv2d(&d, B, h, w, st));
                 } else {
-                    IFL_TRY(conv(L->z1ring, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+                    IFL_TRY(conv(z1, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
                 }
             } else if (!L->raw) {
                 IFL_TRY(conv(L->ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
@@ -498,32 +501,37 @@ extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out
                 const ifl_train_net& N = S.net[i];
                 const float* zsrc = i == 0 ? S.z_a : S.z_mid;
                 float* dzn = L->dz[i];                  // gradient wrt this coupling's input
-                float* dh = L->dh[i];
+                float* dh = N.dh ? N.dh : L->dh[i];
                 float* da = L->d64[0];
-                float* dp = L->d64[1];
-                float* dp1 = N.dp1 ? N.dp1 : dp;        // gradient wrt the first convolution's output
+                float* dp = N.dp2 ? N.dp2 : L->d64[1];  // gradient wrt the 1x1 convolution's output
+                float* dp1 = N.dp1 ? N.dp1 : L->d64[1]; // gradient wrt the first convolution's output
+                const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
                 IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part,
                                            N.dbias_part, B, h, w, C, st));
                 // Conv2dZeros 3x3: a2 -> hraw
-                IFL_TRY(ifl_conv2d_wgrad(N.a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
+                if (wg) IFL_TRY(ifl_conv2d_wgrad(N.a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
                 IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
                 IFL_TRY(ifl_an_relu_bwd(N.p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part, B, h, w, 64, st));
                 // 1x1: a1 -> p2
-                IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
+                if (wg) IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
                 IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
                 IFL_TRY(ifl_k_an_relu_bwd(N.p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
                 // first 3x3: (z1 | ft) -> p1
                 if (N.has_z1) {
                     const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
-                    hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
-                    IFL_LAUNCH_CHECK();
-                    IFL_TRY(ifl_conv2d_wgrad(L->z1ring, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
-                    if (!L->skip_ft_wgrad)
+                    const float* z1 = S.z1;
+                    if (!z1) {                          // not kept by the forward: pack it again
+                        hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
+                        IFL_LAUNCH_CHECK();
+                        z1 = L->z1ring;
+                    }
+                    if (wg) IFL_TRY(ifl_conv2d_wgrad(z1, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
+                    if (wg && !L->skip_ft_wgrad)
                         IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
                     IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring, 32, 9, B, h, w, st));
                     hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring, dzn, npx, h, w, C, L->ch);
                     IFL_LAUNCH_CHECK();
-                } else if (!L->skip_ft_wgrad) {
+                } else if (wg && !L->skip_ft_wgrad) {
                     IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
                 }
                 g = dzn;

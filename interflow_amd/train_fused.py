@@ -53,23 +53,23 @@ class accumulate_into_grad:
 class IflTrainNet(Structure):
     _fields_ = [(k, c_void_p) for k in ("w1", "w2", "w3", "w1t", "w2t", "w3t", "an1_bias", "an1_logs", "an2_bias", "an2_logs",
                                         "bias3", "logs3", "p1", "a1", "p2", "a2", "hraw", "dW1", "dW2", "dW3", "an1_part",
-                                        "an2_part", "dlogs_part", "dbias_part", "ldpart", "dp1")] + \
+                                        "an2_part", "dlogs_part", "dbias_part", "ldpart", "dp1", "dp2", "dh")] + \
                [(k, c_int32) for k in ("c0", "n", "hstride", "has_z1", "p1_stride", "pad_")]
 
 
 class IflTrainStep(Structure):
-    _fields_ = [(k, c_void_p) for k in ("M", "c", "dM_part", "z_in", "z_a", "z_mid", "z_out")] + \
+    _fields_ = [(k, c_void_p) for k in ("M", "c", "dM_part", "z_in", "z_a", "z_mid", "z_out", "z1")] + \
                [("cond", c_int32), ("pad_", c_int32), ("net", IflTrainNet * 2)]
 
 
 class IflTrainLevel(Structure):
-    _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch")] + \
+    _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch", "skip_step_wgrad", "pad2_")] + \
                [("eps", c_float), ("skip_ft_wgrad", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
                 ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
                 ("raw", c_void_p), ("raw_step", c_int64)]
 
 
-assert ctypes.sizeof(IflTrainNet) == 232 and ctypes.sizeof(IflTrainStep) == 528 and ctypes.sizeof(IflTrainLevel) == 152
+assert ctypes.sizeof(IflTrainNet) == 248 and ctypes.sizeof(IflTrainStep) == 568 and ctypes.sizeof(IflTrainLevel) == 160
 
 
 PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode", "<i4"), ("cout_real", "<i4"),
@@ -86,6 +86,10 @@ USE_BULK = True
 # and of the saved output gradients, 36 plain GEMMs over the tiles (torch.bmm = rocBLAS), map back to 3x3 taps
 # (ifl_wino4_kmajor / ifl_wino4_dw): 4x fewer multiplications than the direct weight-gradient kernel.
 WINO_WGRAD = True
+# The coupling networks' other weight gradients (last 3x3, 1x1, z1 taps -- and the conditioning part when WINO_WGRAD is off) as
+# one launch per kind, network and level over the gradients the backward saved per step (ifl_conv2d_wgrad_batched) instead
+# of one small launch per step.
+BATCHED_WGRAD = True
 WDST_DTYPE = np.dtype([("dst", "<u8"), ("cin", "<i4"), ("zoff", "<i4")])
 
 _bound = False
@@ -115,6 +119,10 @@ def _lib():
         L.ifl_wino4_kmajor.restype = ctypes.c_int
         L.ifl_wino4_dw.argtypes = [c_void_p, c_int64, c_void_p, ctypes.c_int, c_void_p]
         L.ifl_wino4_dw.restype = ctypes.c_int
+        ci = ctypes.c_int
+        L.ifl_conv2d_wgrad_batched.argtypes = [c_void_p, ci, ci, ci, c_int64, c_void_p, ci, ci, ci, c_int64, c_void_p, ci, ci, c_int64,
+                                               ci, ci, ci, ci, ci, c_void_p]
+        L.ifl_conv2d_wgrad_batched.restype = ctypes.c_int
         _bound = True
     return L
 
@@ -128,7 +136,7 @@ def _net_params(seq):
 class LevelPlan:
     """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
 
-    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True):
+    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True, batched=True):
         L = _lib()
         self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
         self.busy = False
@@ -179,10 +187,16 @@ class LevelPlan:
             self.raw = zeros(nc, B, h + 2, w + 2, 128)
         else:
             self.bulk = False
-        self.wino_wgrad = bool(wino_wgrad) and self.bulk
+        self.wino_wgrad = bool(wino_wgrad) and self.bulk and nc > 0
+        self.batched = bool(batched) and nc > 0
+        if self.wino_wgrad or self.batched:
+            self.dp1 = zeros(nc * 2, B, h + 2, w + 2, 64)                # gradient wrt p1 of every (step, network), zero rings
+        if self.batched:
+            self.dp2 = zeros(nc * 2, B, h + 2, w + 2, 64)
+            self.dh_all = [zeros(nc, B, h + 2, w + 2, hs) for hs in self.hstride]
+            self.z1_all = zeros(nc, B, h + 2, w + 2, 32)
         if self.wino_wgrad:
             K = int(L.ifl_wino4_tiles(B, h, w))
-            self.dp1 = zeros(nc * 2, B, h + 2, w + 2, 64)                # gradient wrt p1 of every (step, network), zero rings
             self.Vt = zeros(36, N_RRDB_CH, K)
             self.dM = zeros(36, nc * 2 * 64, K)
             self.dU = zeros(36, nc * 2 * 64, N_RRDB_CH)
@@ -197,6 +211,8 @@ class LevelPlan:
         # ---- descriptors ----
         self.c_steps = (IflTrainStep * ns)()
         pack_rows, grad_rows, wdst_rows = [], [], []
+        self.dW_first = []                                              # per network: dense gradient pointers of the first conditional step
+        self.per_g = per_g
         self.param_slices = []                                          # per parameter of the function: how to find its gradient
         zi, ci = 0, 0
         wo = go = ro = 0
@@ -212,6 +228,8 @@ class LevelPlan:
                 zi += 1
                 continue
             S.z_a, S.z_mid, S.z_out = ptr(self.z[zi + 1]), ptr(self.z[zi + 2]), ptr(self.z[zi + 3])
+            if self.batched:
+                S.z1 = ptr(self.z1_all[ci])
             zi += 3
             for i, (name, c0, n, z1) in enumerate(self.nets):
                 N = S.net[i]
@@ -244,8 +262,12 @@ class LevelPlan:
                 N.an1_part, N.an2_part = ptr(self.an_part[ci, i, 0]), ptr(self.an_part[ci, i, 1])
                 N.dlogs_part, N.dbias_part = ptr(self.cpl_part[i][ci, 0]), ptr(self.cpl_part[i][ci, 1])
                 N.ldpart = ptr(self.ldpart[ci, i])
-                if self.wino_wgrad:
+                if self.wino_wgrad or self.batched:
                     N.dp1 = ptr(self.dp1[ci * 2 + i])
+                if self.batched:
+                    N.dp2, N.dh = ptr(self.dp2[ci * 2 + i]), ptr(self.dh_all[i][ci])
+                    if ci == 0:
+                        self.dW_first.append((ptr(gv[0]), ptr(gv[1]), ptr(gv[2])))
                 N.c0, N.n, N.hstride, N.has_z1 = c0, n, hs, 1 if z1 else 0
                 r0, p0 = (ch, 32) if z1 else (0, 0)
                 common1 = dict(cout_real=64, cout_pad=64, taps=9, real0=r0, pad0=p0, real1=N_RRDB_CH, pad1=N_RRDB_CH)
@@ -305,6 +327,8 @@ class LevelPlan:
         lv.steps = ctypes.cast(self.c_steps, POINTER(IflTrainStep))
         if self.bulk:
             lv.raw, lv.raw_step = ptr(self.raw), self.raw[0].numel()
+        if self.batched:
+            lv.skip_step_wgrad = 1
         if self.wino_wgrad:
             lv.skip_ft_wgrad = 1
             arr = np.zeros(len(wdst_rows), dtype=WDST_DTYPE)
@@ -313,6 +337,28 @@ class LevelPlan:
             self.wdst = torch.from_numpy(arr.view(np.uint8)).to(device)
         self.level = lv
         self.nc = nc
+
+    def batched_wgrads(self, ft_ring):
+        """The coupling networks' weight gradients of all conditional steps, one launch per (kind, network)."""
+        L = _lib()
+        B, h, w, nc = self.B, self.h, self.w, self.nc
+        st = hip._stream()
+        p64 = self.dp1[0].numel()
+
+        def go(x, xs, cin, xz, dy, dys, cout, dyz, dW, cin_total, ci0, taps):
+            hip.check(L.ifl_conv2d_wgrad_batched(x, xs, 0, cin, xz, dy, dys, 0, cout, dyz, dW, cin_total, ci0, self.per_g, nc, taps,
+                                                 B, h, w, st), "ifl_conv2d_wgrad_batched")
+        for i, (_, _, _, z1) in enumerate(self.nets):
+            hs = self.hstride[i]
+            dW1, dW2, dW3 = self.dW_first[i]
+            astep = self.act.stride(0)
+            go(hip._ptr(self.act[0, i, 3]), 64, 64, astep, hip._ptr(self.dh_all[i]), hs, hs, self.dh_all[i][0].numel(), dW3, 64, 0, 9)
+            go(hip._ptr(self.act[0, i, 1]), 64, 64, astep, hip._ptr(self.dp2[i]), 64, 64, 2 * p64, dW2, 64, 0, 1)
+            cin_total = (32 if z1 else 0) + N_RRDB_CH
+            if z1:
+                go(hip._ptr(self.z1_all), 32, 32, self.z1_all[0].numel(), hip._ptr(self.dp1[i]), 64, 64, 2 * p64, dW1, cin_total, 0, 9)
+            if not self.wino_wgrad:
+                go(hip._ptr(ft_ring), N_RRDB_CH, N_RRDB_CH, 0, hip._ptr(self.dp1[i]), 64, 64, 2 * p64, dW1, cin_total, 1 if z1 else 0, 9)
 
     def matches(self, params):
         return len(params) == len(self.param_ptrs) and all(p.data_ptr() == q for p, q in zip(params, self.param_ptrs))
@@ -373,6 +419,8 @@ class _LevelFn(torch.autograd.Function):
             plan.dW.zero_()
             hip.check(L.ifl_train_level_bwd(ctypes.byref(plan.level), hip._ptr(gz), hip._ptr(gld), hip._ptr(plan.dz_in), hip._stream()),
                       "ifl_train_level_bwd")
+            if plan.batched:
+                plan.batched_wgrads(ctx.ft_ring)
             plan.run_table(plan.grad_tab)
             if plan.wino_wgrad:
                 rows = plan.dM.shape[1]
@@ -450,7 +498,7 @@ def usable(fu, feats) -> bool:
 
 def _plan_for(fu, level, steps, B, h, w, C, device, params):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device), USE_BULK, WINO_WGRAD)
+    key = (level, B, h, w, C, str(device), BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:
@@ -458,7 +506,7 @@ def _plan_for(fu, level, steps, B, h, w, C, device, params):
             return p
     if len(plans) >= MAX_PLANS_PER_SHAPE:
         return None
-    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD)
+    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD, batched=BATCHED_WGRAD)
     plans.append(p)
     return p
 

@@ -180,10 +180,10 @@ def test_fused_level_training_vs_oracle():
     assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
-    # the level drivers with every first convolution in the direct form (no Winograd bulk launch), and with the Winograd
-    # forward but the direct weight-gradient kernel
+    # the level drivers with every first convolution in the direct form (no Winograd bulk launch), with the Winograd forward
+    # but the direct weight-gradient kernel, and with one weight-gradient launch per step instead of the batched ones
     from interflow_amd import train_fused
-    for attr in ("USE_BULK", "WINO_WGRAD"):
+    for attr in ("USE_BULK", "WINO_WGRAD", "BATCHED_WGRAD"):
         setattr(train_fused, attr, False)
         try:
             z4, nll4, ld4, _, loss4 = step()
