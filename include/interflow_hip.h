@@ -315,8 +315,11 @@ typedef struct ifl_train_step {
 
 typedef struct ifl_train_level {
     int32_t B, h, w, C, ch, nsteps, branch, ft_ch;   /* ch = C/2 channels feed the networks; branch as ifl_coupling_fwd         */
-    int32_t skip_step_wgrad, pad2_;              /* != 0: the backward leaves ALL weight gradients of the coupling networks to the
+    int32_t skip_step_wgrad;                     /* != 0: the backward leaves ALL weight gradients of the coupling networks to the
                                                     caller (batched launches over the saved dp1 / dp2 / dh / z1 afterwards)       */
+    int32_t groups;                              /* 2: samples [0, B/2) and [B/2, B) run as two concurrent chains (the caller's
+                                                    stream and a library-owned one); per-block partial sums (an*_part, dM_part)
+                                                    then hold group 0's blocks followed by group 1's; else one chain              */
     float eps;  int32_t skip_ft_wgrad;           /* != 0: the backward leaves the first convolutions' weight gradient wrt ft
                                                     to the caller (ifl_wino4_kmajor + GEMM + ifl_wino4_dw over the saved dp1)     */
     const float* ft;                             /* conditioning features, ringed, ft_ch channels (no gradient towards them)     */

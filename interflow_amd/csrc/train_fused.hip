@@ -20,6 +20,7 @@
 //               parameters' layout
 #include "ifl_common.h"
 #include "../../include/interflow_hip.h"
+#include <mutex>
 
 int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream);
 int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
@@ -444,102 +445,199 @@ extern "C" int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float
     return 0;
 }
 
-extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
+// ---- sample groups ---------------------------------------------------------------------------------------------------------
+// Samples are independent, and at batch 8 every kernel of the chain is latency-bound (a step takes the same time at batch 2):
+// with L->groups == 2 the batch is cut in two halves that run the same chain on two streams (the caller's and one
+// library-owned per device), forked and joined with events.  Everything a group touches is a sample range of the
+// level's buffers; per-block partial sums take the ranges [group 0's blocks | group 1's blocks].
+namespace {
+
+struct TrainFork { hipStream_t aux = nullptr; hipEvent_t fork = nullptr, join = nullptr; std::mutex mu; };
+TrainFork g_tfork[IFL_MAX_DEVICES];
+
+int train_fork(TrainFork** out)
 {
-    IFL_TRY(check_level(L));
-    hipStream_t st = (hipStream_t)stream;
-    const int B = L->B, h = L->h, w = L->w, C = L->C;
-    const int64_t npx = (int64_t)B * h * w;
-    int cstep = -1;                           // index among the conditional steps (the bulk slab's)
-    for (int s = 0; s < L->nsteps; ++s) {
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    IFL_CHECK_ARG(dev >= 0 && dev < IFL_MAX_DEVICES, IFL_ENOTSUP, "device %d", dev);
+    TrainFork& f = g_tfork[dev];
+    if (!f.aux) {
+        IFL_HIP(hipStreamCreateWithFlags(&f.aux, hipStreamNonBlocking));
+        IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+        IFL_HIP(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+    }
+    *out = &f;
+    return 0;
+}
+
+struct Grp { int b0, Bg, idx; int64_t an_blk0, aff_blk0; };    // sample range; first partial-sum block of the group
+
+// one step of one group; cstep = the step's index among the conditional steps (the bulk slab's)
+int fwd_step(const ifl_train_level* L, const Grp& G, int s, int cstep, hipStream_t st)
+{
+    const int B = G.Bg, h = L->h, w = L->w, C = L->C;
+    const int64_t npx = (int64_t)B * h * w, plane = (int64_t)(h + 2) * (w + 2);
+    const int64_t zo = (int64_t)G.b0 * h * w * C, ro = (int64_t)G.b0 * plane;     // offsets of the group in z buffers / ringed pixels
+    const int nblk_c = ifl_coupling_blocks(h, w);
+    {
         const ifl_train_step& S = L->steps[s];
-        IFL_TRY(affine_fwd(S.z_in, S.z_a, S.M, S.c, npx, C, st));
-        if (!S.cond) continue;
-        ++cstep;
+        IFL_TRY(affine_fwd(S.z_in + zo, S.z_a + zo, S.M, S.c, npx, C, st));
+        if (!S.cond) return 0;
         for (int i = 0; i < 2; ++i) {
             const ifl_train_net& N = S.net[i];
-            const float* zsrc = i == 0 ? S.z_a : S.z_mid;
-            float* zdst = i == 0 ? S.z_mid : S.z_out;
+            const float* zsrc = (i == 0 ? S.z_a : S.z_mid) + zo;
+            float* zdst = (i == 0 ? S.z_mid : S.z_out) + zo;
+            const float* p1 = N.p1 + ro * N.p1_stride;
+            float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
+            const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
             if (N.has_z1) {
-                float* z1 = S.z1 ? S.z1 : L->z1ring;
+                float* z1 = (S.z1 ? S.z1 : L->z1ring) + ro * 32;
                 hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, z1, npx, h, w, C, L->ch);
                 IFL_LAUNCH_CHECK();
                 if (L->raw) {                 // z1's taps here, the conditioning part from the bulk slab
                     ifl_conv_desc d = {};
                     d.src[0] = z1; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
-                    d.w = N.w1; d.out = N.p1; d.out_stride = 64; d.cout = 64; d.taps = 9;
-                    d.res1 = L->raw + (int64_t)cstep * L->raw_step; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
+                    d.w = N.w1; d.out = N.p1 + ro * 64; d.out_stride = 64; d.cout = 64; d.taps = 9;
+                    d.res1 = L->raw + (int64_t)cstep * L->raw_step + ro * 128; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
                     IFL_TRY(ifl_conv2d(&d, B, h, w, st));
                 } else {
-                    IFL_TRY(conv(z1, 32, L->ft, L->ft_ch, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+                    IFL_TRY(conv(z1, 32, ft, L->ft_ch, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
                 }
             } else if (!L->raw) {
-                IFL_TRY(conv(L->ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1, 64, 9, B, h, w, st));
+                IFL_TRY(conv(ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
             }
-            IFL_TRY(ifl_k_an_relu_fwd(N.p1, N.p1_stride, N.a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
-            IFL_TRY(conv(N.a1, 64, nullptr, 0, N.w2, nullptr, N.p2, 64, 1, B, h, w, st));
-            IFL_TRY(ifl_an_relu_fwd(N.p2, N.a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
-            IFL_TRY(conv(N.a2, 64, nullptr, 0, N.w3, N.bias3, N.hraw, N.hstride, 9, B, h, w, st));
-            IFL_TRY(ifl_coupling_fwd(zsrc, zdst, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart, B, h, w, C, st));
+            IFL_TRY(ifl_k_an_relu_fwd(p1, N.p1_stride, a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
+            IFL_TRY(conv(a1, 64, nullptr, 0, N.w2, nullptr, p2, 64, 1, B, h, w, st));
+            IFL_TRY(ifl_an_relu_fwd(p2, a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
+            IFL_TRY(conv(a2, 64, nullptr, 0, N.w3, N.bias3, hraw, N.hstride, 9, B, h, w, st));
+            IFL_TRY(ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
+                                     B, h, w, C, st));
         }
     }
     return 0;
+}
+
+// one step of one group; *gp = the gradient wrt the step's output on entry, wrt its input on return
+int bwd_step(const ifl_train_level* L, const Grp& G, int s, const float** gp, const float* dld, float* dz_in, hipStream_t st)
+{
+    const int B = G.Bg, h = L->h, w = L->w, C = L->C;
+    const int64_t npx = (int64_t)B * h * w, plane = (int64_t)(h + 2) * (w + 2);
+    const int64_t zo = (int64_t)G.b0 * h * w * C, ro = (int64_t)G.b0 * plane;
+    const int nblk_c = ifl_coupling_blocks(h, w);
+    const float* g = *gp;
+    if (dld) dld += G.b0;
+    {
+        const ifl_train_step& S = L->steps[s];
+        if (S.cond) {
+            for (int i = 1; i >= 0; --i) {
+                const ifl_train_net& N = S.net[i];
+                const float* zsrc = (i == 0 ? S.z_a : S.z_mid) + zo;
+                float* dzn = L->dz[i] + zo;             // gradient wrt this coupling's input
+                float* dh = (N.dh ? N.dh : L->dh[i]) + ro * N.hstride;
+                float* da = L->d64[0] + ro * 64;
+                float* dp = (N.dp2 ? N.dp2 : L->d64[1]) + ro * 64;  // gradient wrt the 1x1 convolution's output
+                float* dp1 = (N.dp1 ? N.dp1 : L->d64[1]) + ro * 64; // gradient wrt the first convolution's output
+                const float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
+                const float* p1 = N.p1 + ro * N.p1_stride;
+                const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
+                const int64_t co = (int64_t)G.b0 * nblk_c * 2 * N.n;
+                const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
+                IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part + co,
+                                           N.dbias_part + co, B, h, w, C, st));
+                // Conv2dZeros 3x3: a2 -> hraw
+                if (wg) IFL_TRY(ifl_conv2d_wgrad(a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
+                IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
+                IFL_TRY(ifl_an_relu_bwd(p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part + G.an_blk0 * 128, B, h, w, 64, st));
+                // 1x1: a1 -> p2
+                if (wg) IFL_TRY(ifl_conv2d_wgrad(a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
+                IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
+                IFL_TRY(ifl_k_an_relu_bwd(p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part + G.an_blk0 * 128, B, h, w, 64, st));
+                // first 3x3: (z1 | ft) -> p1
+                if (N.has_z1) {
+                    const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
+                    const float* z1 = S.z1 ? S.z1 + ro * 32 : nullptr;
+                    if (!z1) {                          // not kept by the forward: pack it again
+                        hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring + ro * 32, npx, h, w, C, L->ch);
+                        IFL_LAUNCH_CHECK();
+                        z1 = L->z1ring + ro * 32;
+                    }
+                    if (wg) IFL_TRY(ifl_conv2d_wgrad(z1, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
+                    if (wg && !L->skip_ft_wgrad)
+                        IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
+                    IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring + ro * 32, 32, 9, B, h, w, st));
+                    hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring + ro * 32, dzn, npx, h, w, C, L->ch);
+                    IFL_LAUNCH_CHECK();
+                } else if (wg && !L->skip_ft_wgrad) {
+                    IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
+                }
+                g = dzn;
+            }
+        }
+        float* out = (s == 0 ? dz_in : L->dz[2 + (s & 1)]) + zo;
+        IFL_TRY(affine_bwd(S.z_in + zo, g, S.M, out, S.dM_part + G.aff_blk0 * (C * C + C), npx, C, st));
+        *gp = out;
+    }
+    return 0;
+}
+
+// The level's one or two sample groups, interleaved step by step (so that both streams have work from the start: the host
+// enqueues about as fast as the device runs these small kernels); two groups: the second on the device's auxiliary stream.
+struct Groups { int n; Grp g[2]; hipStream_t st[2]; TrainFork* f; };
+
+int groups_begin(const ifl_train_level* L, hipStream_t st, Groups* out)
+{
+    Groups& R = *out;
+    R.n = (L->groups == 2 && L->B >= 2) ? 2 : 1;
+    const int B0 = R.n == 2 ? L->B / 2 : L->B;
+    R.g[0] = Grp{0, B0, 0, 0, 0};
+    R.st[0] = R.st[1] = st;
+    R.f = nullptr;
+    if (R.n == 1) return 0;
+    R.g[1] = Grp{B0, L->B - B0, 1, ifl_an_relu_blocks(B0, L->h, L->w), ifl_affine_px_blocks((int64_t)B0 * L->h * L->w)};
+    IFL_TRY(train_fork(&R.f));
+    R.f->mu.lock();                                           // the auxiliary stream and its events are per device
+    R.st[1] = R.f->aux;
+    hipError_t e = hipEventRecord(R.f->fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(R.f->aux, R.f->fork, 0);
+    if (e != hipSuccess) { R.f->mu.unlock(); ifl_set_error("train level fork: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int groups_end(Groups& R, int rc)
+{
+    if (R.n == 1) return rc;
+    hipError_t e = hipEventRecord(R.f->join, R.f->aux);       // always rejoin, whatever the steps returned
+    if (e == hipSuccess) e = hipStreamWaitEvent(R.st[0], R.f->join, 0);
+    R.f->mu.unlock();
+    if (e != hipSuccess && !rc) { ifl_set_error("train level join: %s", hipGetErrorString(e)); rc = (int)e; }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
+{
+    IFL_TRY(check_level(L));
+    Groups R;
+    IFL_TRY(groups_begin(L, (hipStream_t)stream, &R));
+    int rc = 0, cstep = -1;
+    for (int s = 0; s < L->nsteps && !rc; ++s) {
+        if (L->steps[s].cond) ++cstep;
+        for (int k = 0; k < R.n && !rc; ++k) rc = fwd_step(L, R.g[k], s, cstep, R.st[k]);
+    }
+    return groups_end(R, rc);
 }
 
 extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out, const float* dld, float* dz_in, void* stream)
 {
     IFL_TRY(check_level(L));
     IFL_CHECK_ARG(dz_out && dz_in && L->dz[0] && L->dz[1] && L->dz[2] && L->dz[3] && L->d64[0] && L->d64[1], IFL_EINVAL, "train level backward: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int B = L->B, h = L->h, w = L->w, C = L->C;
-    const int64_t npx = (int64_t)B * h * w;
-    const float* g = dz_out;
-    for (int s = L->nsteps - 1; s >= 0; --s) {
-        const ifl_train_step& S = L->steps[s];
-        if (S.cond) {
-            for (int i = 1; i >= 0; --i) {
-                const ifl_train_net& N = S.net[i];
-                const float* zsrc = i == 0 ? S.z_a : S.z_mid;
-                float* dzn = L->dz[i];                  // gradient wrt this coupling's input
-                float* dh = N.dh ? N.dh : L->dh[i];
-                float* da = L->d64[0];
-                float* dp = N.dp2 ? N.dp2 : L->d64[1];  // gradient wrt the 1x1 convolution's output
-                float* dp1 = N.dp1 ? N.dp1 : L->d64[1]; // gradient wrt the first convolution's output
-                const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
-                IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, N.hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part,
-                                           N.dbias_part, B, h, w, C, st));
-                // Conv2dZeros 3x3: a2 -> hraw
-                if (wg) IFL_TRY(ifl_conv2d_wgrad(N.a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
-                IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
-                IFL_TRY(ifl_an_relu_bwd(N.p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part, B, h, w, 64, st));
-                // 1x1: a1 -> p2
-                if (wg) IFL_TRY(ifl_conv2d_wgrad(N.a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
-                IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
-                IFL_TRY(ifl_k_an_relu_bwd(N.p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part, B, h, w, 64, st));
-                // first 3x3: (z1 | ft) -> p1
-                if (N.has_z1) {
-                    const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
-                    const float* z1 = S.z1;
-                    if (!z1) {                          // not kept by the forward: pack it again
-                        hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring, npx, h, w, C, L->ch);
-                        IFL_LAUNCH_CHECK();
-                        z1 = L->z1ring;
-                    }
-                    if (wg) IFL_TRY(ifl_conv2d_wgrad(z1, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
-                    if (wg && !L->skip_ft_wgrad)
-                        IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
-                    IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring, 32, 9, B, h, w, st));
-                    hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring, dzn, npx, h, w, C, L->ch);
-                    IFL_LAUNCH_CHECK();
-                } else if (wg && !L->skip_ft_wgrad) {
-                    IFL_TRY(ifl_conv2d_wgrad(L->ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
-                }
-                g = dzn;
-            }
-        }
-        float* out = s == 0 ? dz_in : L->dz[2 + (s & 1)];
-        IFL_TRY(affine_bwd(S.z_in, g, S.M, out, S.dM_part, npx, C, st));
-        g = out;
-    }
-    return 0;
+    Groups R;
+    IFL_TRY(groups_begin(L, (hipStream_t)stream, &R));
+    const float* gp[2];
+    for (int k = 0; k < R.n; ++k) gp[k] = dz_out + (int64_t)R.g[k].b0 * L->h * L->w * L->C;
+    int rc = 0;
+    for (int s = L->nsteps - 1; s >= 0 && !rc; --s)
+        for (int k = 0; k < R.n && !rc; ++k) rc = bwd_step(L, R.g[k], s, &gp[k], dld, dz_in, R.st[k]);
+    return groups_end(R, rc);
 }

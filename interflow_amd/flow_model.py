@@ -399,6 +399,17 @@ class InterpFlow(nn.Module):
             return epses, nll, logdet
         return z, nll, logdet, ll_ib
 
+    def loss_terms(self, z, logdet, pixels, label):
+        """(nll per sample, ib loss) = calculate_loss followed by train.py:74's -mean(ll_ib), with the mean over the selected
+        entries written as a masked sum: masked_select's output shape depends on the data, i.e. a device-to-host round trip
+        in the middle of the step, which keeps the host from issuing the backward pass while the forward still runs.
+        Same values as calculate_loss (no selected entry at all: 0/0 = NaN, like the mean of an empty tensor)."""
+        ll_all, mask_label, ll = self._class_loglik(z, label)
+        ls = torch.log_softmax(ll_all / float(pixels), dim=1)
+        ib_loss = -(ls * mask_label).sum() / mask_label.sum()
+        nll = (-(logdet + ll)) / float(np.log(2.) * pixels)
+        return nll, ib_loss
+
     def get_lr(self, input_lr, heat=1., test_input_size=None):
         z_shape = (input_lr.shape[0], input_lr.shape[1] * 16, input_lr.shape[2], input_lr.shape[3])
         z = torch.normal(mean=0, std=heat, size=z_shape).to(input_lr.device)

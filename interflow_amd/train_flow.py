@@ -238,7 +238,8 @@ def gaussian_logp(mean, cov, x):
     x_ = x.permute(0, 2, 3, 1)
     x_c = x_ - mean
     k = x.shape[1]
-    cov_inv = torch.inverse(cov)
+    cov_inv = torch.linalg.inv_ex(cov)[0]      # torch.inverse without its host-side error check (a device synchronisation);
+    #                                            a singular covariance gives inf/nan here and the step's loss guard drops the update
     logdet = torch.slogdet(cov)[1]
     lik = -0.5 * (logdet + k * LOG2PI + (torch.matmul(x_c, cov_inv) * x_c).sum(dim=3))
     return lik.sum(dim=(1, 2))

@@ -22,6 +22,7 @@ ActNorm2d (FlowActNorms.py:45-97), InvertibleConv1x1 (Permutations.py:76-123).
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
 
 import numpy as np
@@ -38,6 +39,26 @@ MAX_PLANS_PER_SHAPE = 4        # forwards whose backward is still due, per level
 # for them, instead of returning ~290 tensors per level that autograd clones or adds one by one.  Off by default: a plain
 # `torch.autograd.grad` / `backward` keeps the usual semantics.
 _direct_grad = False
+# ... and do that whole weight-gradient phase of a level (batched weight gradients, the Winograd-domain GEMMs, re-layout,
+# the multi-tensor add) on a second stream, so that it runs beside the next level's sequential chain of small kernels;
+# leaving the `accumulate_into_grad()` block joins that stream.
+SIDE_STREAM = os.environ.get("IFL_TRAIN_SIDE_STREAM", "1") != "0"
+_side = {}
+_pending = set()
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def join_side_streams():
+    """The caller's current stream waits for the weight-gradient work issued on the side streams."""
+    while _pending:
+        s = _pending.pop()
+        torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 class accumulate_into_grad:
@@ -48,6 +69,7 @@ class accumulate_into_grad:
     def __exit__(self, *exc):
         global _direct_grad
         _direct_grad = self.prev
+        join_side_streams()
 
 
 class IflTrainNet(Structure):
@@ -63,7 +85,7 @@ class IflTrainStep(Structure):
 
 
 class IflTrainLevel(Structure):
-    _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch", "skip_step_wgrad", "pad2_")] + \
+    _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch", "skip_step_wgrad", "groups")] + \
                [("eps", c_float), ("skip_ft_wgrad", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
                 ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
                 ("raw", c_void_p), ("raw_step", c_int64)]
@@ -90,6 +112,9 @@ WINO_WGRAD = True
 # one launch per kind, network and level over the gradients the backward saved per step (ifl_conv2d_wgrad_batched) instead
 # of one small launch per step.
 BATCHED_WGRAD = True
+# Samples are independent and the per-step chain is latency-bound at batch 8: the level drivers run the two halves of the
+# batch as two concurrent chains (ifl_train_level.groups).
+GROUPS = int(os.environ.get("IFL_TRAIN_GROUPS", "2"))
 WDST_DTYPE = np.dtype([("dst", "<u8"), ("cin", "<i4"), ("zoff", "<i4")])
 
 _bound = False
@@ -157,8 +182,10 @@ class LevelPlan:
         def zeros(*shape):
             return torch.zeros(*shape, **f32)
 
-        nblk_a = int(L.ifl_affine_px_blocks(B * h * w))
-        nblk_an = int(L.ifl_an_relu_blocks(B, h, w))
+        self.groups = 2 if (GROUPS == 2 and B >= 2) else 1
+        halves = [B // 2, B - B // 2] if self.groups == 2 else [B]
+        nblk_a = sum(int(L.ifl_affine_px_blocks(b * h * w)) for b in halves)        # each group's blocks, one after the other
+        nblk_an = sum(int(L.ifl_an_relu_blocks(b, h, w)) for b in halves)
         nblk_c = int(L.ifl_coupling_blocks(h, w))
         cin1 = [(32 if z1 else 0) + N_RRDB_CH for _, _, _, z1 in self.nets]
         # ---- saved activations and gradients ----
@@ -318,6 +345,7 @@ class LevelPlan:
         lv = IflTrainLevel()
         lv.B, lv.h, lv.w, lv.C, lv.ch, lv.nsteps, lv.branch, lv.ft_ch = B, h, w, C, ch, ns, 1, N_RRDB_CH
         lv.eps = self.eps
+        lv.groups = self.groups
         lv.z1ring, lv.dz1ring = ptr(self.z1ring), ptr(self.dz1ring)
         for k in range(4):
             lv.dz[k] = ptr(self.dzs[k])
@@ -414,47 +442,65 @@ class _LevelFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=plan.device)
         gz = torch.zeros(plan.z_last.shape, **f32) if gz is None else gz.contiguous().float()
         gld = torch.zeros(plan.B, **f32) if gld is None else gld.contiguous().float()
+        C = plan.C
         with torch.cuda.device(plan.device):
             plan.level.ft = ctx.ft_ring.data_ptr() if ctx.ft_ring is not None else None
             plan.dW.zero_()
             hip.check(L.ifl_train_level_bwd(ctypes.byref(plan.level), hip._ptr(gz), hip._ptr(gld), hip._ptr(plan.dz_in), hip._stream()),
                       "ifl_train_level_bwd")
-            if plan.batched:
-                plan.batched_wgrads(ctx.ft_ring)
-            plan.run_table(plan.grad_tab)
-            if plan.wino_wgrad:
-                rows = plan.dM.shape[1]
-                hip.check(L.ifl_wino4_kmajor(0, hip._ptr(ctx.ft_ring), N_RRDB_CH, 1, 0, hip._ptr(plan.Vt), N_RRDB_CH, 0,
-                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
-                hip.check(L.ifl_wino4_kmajor(1, hip._ptr(plan.dp1), 64, plan.dp1.shape[0], plan.dp1[0].numel(), hip._ptr(plan.dM), rows, 0,
-                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
-                torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
-                hip.check(L.ifl_wino4_dw(hip._ptr(plan.dU), rows, hip._ptr(plan.wdst), plan.dp1.shape[0], hip._stream()), "ifl_wino4_dw")
-            C = plan.C
             dMc = plan.dM_part.sum(dim=1)                                  # [steps, C*C + C]
-            an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
-            cpl = [t.sum(dim=2) for t in plan.cpl_part]                    # per network slot: [cond steps, (logs3 | bias3), 2n]
-            grads, dst, src = [], [], []
-            for (kind, where, shape), p in zip(plan.param_slices, plan.params):
-                if kind == "w":
-                    g = where.view(shape)
-                elif kind == "an":
-                    s, i, a, k = where
-                    g = an[s, i, a, k * 64:(k + 1) * 64].reshape(shape)
-                else:
-                    i, s, k = where
-                    g = cpl[i][s, k].reshape(shape)
-                if _direct_grad and p.grad is not None and p.grad.dtype == torch.float32:
-                    dst.append(p.grad)
-                    src.append(g)
-                    grads.append(None)
-                else:
-                    grads.append(g.clone() if kind == "w" else g)
-            if dst:
-                torch._foreach_add_(dst, src)
             dz = plan.dz_in.clone()
+            direct = _direct_grad and all(p.grad is not None and p.grad.dtype == torch.float32 for p in plan.params)
+            if direct and SIDE_STREAM:
+                # everything below only produces parameter gradients: on a second stream, beside the next level's chain
+                main = torch.cuda.current_stream()
+                side = _side_stream(plan.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    grads = _LevelFn._weight_phase(plan, ctx.ft_ring, True)
+                _pending.add(side)
+            else:
+                grads = _LevelFn._weight_phase(plan, ctx.ft_ring, direct)
         ctx.lease.release()
         return (None, None, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
+
+    @staticmethod
+    def _weight_phase(plan, ft_ring, direct):
+        """Weight gradients of the level's coupling networks from what the chain saved, brought into the parameters' layout;
+        `direct`: added into the parameters' .grad here (one multi-tensor add), else returned."""
+        L = _lib()
+        if plan.batched:
+            plan.batched_wgrads(ft_ring)
+        plan.run_table(plan.grad_tab)
+        if plan.wino_wgrad:
+            rows = plan.dM.shape[1]
+            hip.check(L.ifl_wino4_kmajor(0, hip._ptr(ft_ring), N_RRDB_CH, 1, 0, hip._ptr(plan.Vt), N_RRDB_CH, 0,
+                                         plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+            hip.check(L.ifl_wino4_kmajor(1, hip._ptr(plan.dp1), 64, plan.dp1.shape[0], plan.dp1[0].numel(), hip._ptr(plan.dM), rows, 0,
+                                         plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+            torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
+            hip.check(L.ifl_wino4_dw(hip._ptr(plan.dU), rows, hip._ptr(plan.wdst), plan.dp1.shape[0], hip._stream()), "ifl_wino4_dw")
+        an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
+        cpl = [t.sum(dim=2) for t in plan.cpl_part]                    # per network slot: [cond steps, (logs3 | bias3), 2n]
+        grads, dst, src = [], [], []
+        for (kind, where, shape), p in zip(plan.param_slices, plan.params):
+            if kind == "w":
+                g = where.view(shape)
+            elif kind == "an":
+                s, i, a, k = where
+                g = an[s, i, a, k * 64:(k + 1) * 64].reshape(shape)
+            else:
+                i, s, k = where
+                g = cpl[i][s, k].reshape(shape)
+            if direct:
+                dst.append(p.grad)
+                src.append(g)
+                grads.append(None)
+            else:
+                grads.append(g.clone() if kind == "w" else g)
+        if dst:
+            torch._foreach_add_(dst, src)
+        return grads
 
 
 def _affine_maps(steps, C, pixels):
@@ -498,7 +544,7 @@ def usable(fu, feats) -> bool:
 
 def _plan_for(fu, level, steps, B, h, w, C, device, params):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device), BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
+    key = (level, B, h, w, C, str(device), GROUPS, BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:

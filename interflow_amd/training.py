@@ -47,6 +47,7 @@ class GradientAllReducer:
             for p in b["params"]:
                 self._bucket_of[id(p)] = bi
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.defer = False            # True: the hooks launch nothing; finish() reduces every bucket (train_step's late_check)
         self.zero_grad()
 
     def _close(self, plist):
@@ -75,7 +76,7 @@ class GradientAllReducer:
             b["flat"][o:o + p.numel()].copy_(p.grad.reshape(-1))
             p.grad = b["flat"][o:o + p.numel()].view_as(p)
         b["pending"] -= 1
-        if b["pending"] == 0 and not b["launched"]:
+        if b["pending"] == 0 and not b["launched"] and not self.defer:
             self._launch(b)
 
     @staticmethod
@@ -196,11 +197,90 @@ def consistency_loss(model, gt, lr_enc, low_res, img_lr1, scale1, img_lr2, scale
     return torch.nn.functional.l1_loss(synth_down, interp_down).mean()                  # :104-106
 
 
+def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, device):
+    """train_step's tail with the skip guards after the backward pass (see `late_check`)."""
+    from .train_fused import accumulate_into_grad
+    dist = reducer.dist if reducer is not None else None
+    if reducer is not None:
+        reducer.zero_grad()
+        reducer.defer = True                    # the hooks only collect; finish() launches the all-reduces after the decision
+    else:
+        optimizer.zero_grad()
+    try:
+        with accumulate_into_grad():
+            loss.backward()                                                             # train.py:129
+    finally:
+        if reducer is not None:
+            reducer.defer = False
+    terms = torch.stack([loss.detach(), nll_loss.detach(), ib_loss.detach(), cons.detach()]).tolist()    # the step's one host read
+    bad = (terms[0] != terms[0] or abs(terms[0]) == float("inf")) or (step > 100 and terms[0] > 30)     # :113-126
+    if dist is not None and dist.get_world_size() > 1:
+        flag = torch.tensor([1.0 if bad else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = bool(flag.item() > 0)
+    if bad:
+        out["skipped"] = True
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            optimizer.zero_grad()
+    else:
+        if reducer is not None:
+            reducer.finish()
+        optimizer.step()                                                                # :130
+        if scheduler is not None:
+            scheduler.step()                                                            # :131
+    out.update(loss=terms[0], nll=terms[1], ib_loss=terms[2], consistency_loss=terms[3])
+    return out
+
+
+class EncoderPrefetcher:
+    """The frozen conditioning encoder one batch ahead, on a stream of its own.
+
+    With the encoder frozen its features depend on the data only, so the encoder pass of batch n+1 (345 small dependent
+    convolutions, latency-bound at batch 8) can run while batch n goes through the flow and its backward pass -- also
+    chains of small kernels -- instead of in front of them: `submit(gt_next)` before `train_step(..., lr_enc=get())`.
+    Every step still runs its own encoder pass on the device; only the order of issue changes.  Refuses to work when
+    gradients have to reach the encoder (then the features belong to the step's autograd graph)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.stream = torch.cuda.Stream()
+        self.pending = None
+
+    def submit(self, gt):
+        assert self.pending is None, "one batch ahead: get() the previous features first"
+        arch = self.model.arch
+        if any(p.requires_grad for p in arch.RRDB.parameters()):
+            raise RuntimeError("EncoderPrefetcher needs a frozen encoder (arch.set_rrdb_training(False))")
+        self.stream.wait_stream(torch.cuda.current_stream(gt.device))      # gt, and every earlier use of the encoder's buffers
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            feats = arch.rrdbPreprocessing(gt)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.pending = (feats, done, gt)
+
+    def get(self):
+        feats, done, _gt = self.pending
+        self.pending = None
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        for t in feats.values():
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)                                       # allocated on the side stream, consumed here
+        return feats
+
+
 def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, reducer: Optional[GradientAllReducer] = None,
                scheduler=None, step: int = 0, add_gt_noise: bool = True, consistency_lambda: float = 0.0, interp=None,
-               interpolate_weight=None):
+               interpolate_weight=None, lr_enc=None, late_check: bool = False):
     """One iteration of train.py:66-131.  interp = (img_lr1, scale1, img_lr2, scale2) enables the LR-consistency term
-    (weight consistency_lambda; train.py's default is 10).  Returns a dict of python floats (this synchronises, as the
+    (weight consistency_lambda; train.py's default is 10).  lr_enc: the conditioning features of `gt` when the caller has
+    them already (`EncoderPrefetcher`).  late_check: evaluate the reference's skip guards AFTER the backward pass instead of
+    before it (train.py:113-126 reads the loss on the host first): the step then has no device synchronisation between the
+    forward and the backward pass, so the host issues the backward while the forward still runs; a skipped step has then
+    computed gradients that nobody applies, and in data-parallel runs the all-reduce is launched only after the collective
+    decision (no overlap with the backward, and never fed with a skipped step's gradients).  Returns a dict of python floats (this synchronises, as the
     reference's progress bar does at train.py:133-134) and `skipped`.
 
     Data parallel (reducer given): uninitialised ActNorms are initialised and broadcast first (`init_actnorm`), and the
@@ -210,9 +290,14 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
     dist = reducer.dist if reducer is not None else None
     if model.training:
         init_actnorm(model, gt, low_res, dist)
-    lr_enc = model.arch.rrdbPreprocessing(gt)                                           # train.py:72
-    z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc, add_gt_noise=add_gt_noise)     # :73
-    ib_loss = -torch.mean(ll_ib)                                                        # :74
+    if lr_enc is None:                                                                  # (given: EncoderPrefetcher's features of gt)
+        lr_enc = model.arch.rrdbPreprocessing(gt)                                       # train.py:72
+    if late_check:
+        z, logdet = model(low_res, gt, lr_enc=lr_enc, add_gt_noise=add_gt_noise, calc_loss=False)    # :73
+        nll, ib_loss = model.loss_terms(z, logdet, int(gt.size(2) * gt.size(3)), labels)             # :74
+    else:
+        z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc, add_gt_noise=add_gt_noise)     # :73
+        ib_loss = -torch.mean(ll_ib)                                                    # :74
     nll_loss = torch.mean(nll)                                                          # :75
     if consistency_lambda > 0 and interp is not None:                                   # :78-106
         cons = consistency_loss(model, gt, lr_enc, low_res, *interp, interpolate_weight=interpolate_weight,
@@ -221,6 +306,8 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
         cons = torch.zeros((), device=gt.device)                                        # :107-108
     loss = nll_loss + consistency_lambda * cons + ib_lambda * ib_loss                   # :110
     out = {"skipped": False}
+    if late_check:
+        return _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, gt.device)
     bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss.detach()) > 30)         # :113-126
     if dist is not None and dist.get_world_size() > 1:
         flag = torch.tensor([1.0 if bad else 0.0], device=gt.device)

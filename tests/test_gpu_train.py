@@ -181,14 +181,15 @@ def test_fused_level_training_vs_oracle():
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
     # the level drivers with every first convolution in the direct form (no Winograd bulk launch), with the Winograd forward
-    # but the direct weight-gradient kernel, and with one weight-gradient launch per step instead of the batched ones
+    # but the direct weight-gradient kernel, with one weight-gradient launch per step instead of the batched ones, and with
+    # one chain per level instead of two concurrent sample groups
     from interflow_amd import train_fused
-    for attr in ("USE_BULK", "WINO_WGRAD", "BATCHED_WGRAD"):
-        setattr(train_fused, attr, False)
+    for attr, off, on in (("USE_BULK", False, True), ("WINO_WGRAD", False, True), ("BATCHED_WGRAD", False, True), ("GROUPS", 1, 2)):
+        setattr(train_fused, attr, off)
         try:
             z4, nll4, ld4, _, loss4 = step()
         finally:
-            setattr(train_fused, attr, True)
+            setattr(train_fused, attr, on)
         assert rel(z4, z) < 1e-5 and rel(ld4, ld) < 1e-5 and rel(loss4, loss) < 1e-5
         for k, g in fused.items():
             assert rel(named[k].grad, g) < 2e-4, (attr, k)

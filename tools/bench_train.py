@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--patch", type=int, default=160)
     ap.add_argument("--consistency", action="store_true", help="add the LR-consistency term (train.py's default lambda 10)")
+    ap.add_argument("--prefetch-encoder", action="store_true",
+                    help="with --frozen-rrdb: the encoder pass of the next batch on its own stream, overlapping this step (training.EncoderPrefetcher)")
+    ap.add_argument("--late-check", action="store_true", help="train_step(late_check=True): no host read of the loss before the backward pass")
     ap.add_argument("--frozen-rrdb", action="store_true", help="do not train the conditioning encoder (no gradient wrt ft)")
     args = ap.parse_args()
     rank, local_rank, world = shard.dist_env()
@@ -51,18 +54,34 @@ def main():
     if args.consistency:
         kw = dict(consistency_lambda=10.0, interp=(torch.rand(B, 3, P, P, device=dev, generator=g), 2,
                                                    torch.rand(B, 3, P, P, device=dev, generator=g), 4))
+    if args.late_check:
+        kw["late_check"] = True
+    if args.prefetch_encoder:
+        assert args.frozen_rrdb, "--prefetch-encoder needs --frozen-rrdb"
+        training.init_actnorm(model, gt, lr, dist)
+        pf = training.EncoderPrefetcher(model)
+        pf.submit(gt)
+
+        def step_fn():
+            feats = pf.get()
+            pf.submit(gt)                                   # the next batch's encoder pass (here: the same synthetic batch again)
+            return training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, lr_enc=feats, **kw)
+    else:
+        step_fn = lambda: training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, **kw)
     for _ in range(args.warmup):
-        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, **kw)
+        out = step_fn()
     shard.barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, **kw)
+        out = step_fn()
     shard.barrier(dist, dev)
     dt = shard.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
     def sync():
         torch.cuda.synchronize(dev)
         return time.perf_counter()
+    if args.prefetch_encoder:
+        pf.get()
     t = [sync()]
     lr_enc = model.arch.rrdbPreprocessing(gt); t.append(sync())
     z, nll, ld, ll_ib = model(lr, gt, labels, lr_enc=lr_enc); t.append(sync())
@@ -72,7 +91,9 @@ def main():
     ranks = shard.rank_devices(dist, dev)
     if rank == 0:
         print(json.dumps({"workload": f"training step (NLL + ib; forward, backward, Adam), batch {B} of {P}x{P} per GPU, fp32, "
-                                      f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained'}{', with LR-consistency term' if args.consistency else ''}",
+                                      f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained'}{', with LR-consistency term' if args.consistency else ''}"
+                                      f"{', encoder pass of the next batch overlapped on a second stream' if args.prefetch_encoder else ''}"
+                                      f"{', loss guards after the backward pass' if args.late_check else ''}",
                           "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
                           "ranks": ranks, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                           "patches_per_s": B * world * args.steps / dt, "last": out,
