@@ -223,6 +223,10 @@ typedef struct ifl_conv_desc {
     const float* res2; int32_t res2_stride, res2_off; float beta;
 } ifl_conv_desc;
 int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream);
+/* nz convolutions of one shape in one launch (the same layer of nz flow steps): problem k uses src[i] + k*src_i_z, w + k*w_z,
+ * bias + k*bias_z, res1 + k*res1_z and writes out + k*out_z (strides in floats; B * nz <= 65535; no res2).              */
+int ifl_conv2d_batched(const ifl_conv_desc* d, int nz, int64_t src0_z, int64_t src1_z, int64_t w_z, int64_t bias_z,
+                       int64_t out_z, int64_t res1_z, int B, int h, int w, void* stream);
 int ifl_conv2d_wgrad(const float* x, int x_stride, int x_off, int cin, const float* dy, int dy_stride, int dy_off, int cout,
                      float* dW, int cin_total, int ci0, int taps, int B, int h, int w, void* stream);
 /* nz independent weight gradients of one shape in one launch (the same convolution of nz flow steps): problem k reads
@@ -328,6 +332,14 @@ typedef struct ifl_train_level {
     float *dh[2];                                /* scratch per network slot, ringed hstride channels, zero outside rows [0,2n)  */
     float *d64[2];                               /* scratch, ringed 64 channels, zero ring                                       */
     const ifl_train_step* steps;                 /* host array [nsteps]                                                          */
+    /* z-independent network (has_z1 == 0) batched over the steps -- needs raw, skip_step_wgrad and per-step dp1 / dp2 / dh:
+     * its ActNorm+ReLU, 1x1 and last convolution run as ONE launch each for all conditional steps before the chain
+     * (forward) and after it (backward: data gradients back to dp1), so the sequential chain only applies its coupling.  */
+    const float* anp;                            /* that network's ActNorm parameters per conditional step, anp_step floats
+                                                    apart: [an1 bias | an1 logs | an2 bias | an2 logs] x 64                   */
+    int64_t anp_step;
+    float* da_all;                               /* scratch [conditional steps][B][h+2][w+2][64], zero rings                  */
+    int32_t f_batched, pad3_;
     const float* raw;                            /* optional: ifl_train_bulk_conv1's slabs [conditional step][B][h+2][w+2][128]; then
                                                     w1 of a network with z1 holds the 32 z1 input channels only and p1 = its z1
                                                     taps + raw[.., 0:64]; a network without z1 has p1 = raw + 64, p1_stride 128  */

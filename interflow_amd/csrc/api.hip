@@ -747,7 +747,24 @@ extern "C" int ifl_unsqueeze2d(const float* in, float* out, int B, int C, int H,
     return ifl_k_squeeze_nchw(in, out, B, C / (factor * factor), H * factor, W * factor, factor, 1, (hipStream_t)stream);
 }
 
+static int conv2d_impl(const ifl_conv_desc* d, int nz, const int64_t* zs, int B, int h, int w, void* stream);
+
 extern "C" int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* stream)
+{
+    return conv2d_impl(d, 1, nullptr, B, h, w, stream);
+}
+
+extern "C" int ifl_conv2d_batched(const ifl_conv_desc* d, int nz, int64_t src0_z, int64_t src1_z, int64_t w_z, int64_t bias_z,
+                                  int64_t out_z, int64_t res1_z, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(nz >= 1 && src0_z % 4 == 0 && src1_z % 4 == 0 && w_z % 4 == 0 && bias_z % 4 == 0 && out_z % 4 == 0 && res1_z % 4 == 0,
+                  IFL_EINVAL, "batched conv: %d problems, strides must be multiples of 4 floats", nz);
+    IFL_CHECK_ARG(d && !d->res2, IFL_ENOTSUP, "batched conv: no second residual");
+    const int64_t zs[6] = {src0_z, src1_z, w_z, bias_z, out_z, res1_z};
+    return conv2d_impl(d, nz, zs, B, h, w, stream);
+}
+
+static int conv2d_impl(const ifl_conv_desc* d, int nz, const int64_t* zs, int B, int h, int w, void* stream)
 {
     IFL_CHECK_ARG(d && d->w && d->out && d->src[0], IFL_EINVAL, "null pointer");
     IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape B=%d h=%d w=%d", B, h, w);
@@ -766,6 +783,10 @@ extern "C" int ifl_conv2d(const ifl_conv_desc* d, int B, int h, int w, void* str
     a.res1 = d->res1; a.res1_stride = d->res1_stride; a.res1_off = d->res1_off; a.alpha = d->alpha;
     a.res2 = d->res2; a.res2_stride = d->res2_stride; a.res2_off = d->res2_off; a.beta = d->beta;
     a.g = ifl_choose_geom(h, w);
+    if (nz > 1) {
+        a.nz = nz; a.Bz = B;
+        a.z_src[0] = zs[0]; a.z_src[1] = zs[1]; a.z_w = zs[2]; a.z_bias = zs[3]; a.z_out = zs[4]; a.z_res1 = zs[5];
+    }
     return ifl_k_convg(a, B, (hipStream_t)stream);
 }
 

@@ -32,7 +32,20 @@ void convg_kernel(IflConvArgs a)
     const IflGeom& g = a.g;
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;
-    const int b = blockIdx.y, grp = blockIdx.z;
+    int b = blockIdx.y;
+    const int grp = blockIdx.z;
+    const float *src0 = a.src[0], *src1 = a.src[1], *wbase = a.w, *biasp = a.bias, *res1p = a.res1;
+    float* outp = a.out;
+    if (a.nz > 1) {                                               // batched: problem z of nz
+        const int z = b / a.Bz;
+        b -= z * a.Bz;
+        src0 += z * a.z_src[0];
+        if (src1) src1 += z * a.z_src[1];
+        wbase += z * a.z_w;
+        if (biasp) biasp += z * a.z_bias;
+        if (res1p) res1p += z * a.z_res1;
+        outp += z * a.z_out;
+    }
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -78,12 +91,12 @@ void convg_kernel(IflConvArgs a)
     constexpr int KQW = HALF ? 2 : 4;                             // ... of which this wave multiplies KQW
     // weights: one record per 32 output channels, [chunk][tap][kq][64 lanes x 4]; this workgroup reads records grp*MT .. +MT
     const int64_t wrec = (int64_t)nchunks * (TAPS * KQ * 256);
-    const float* wl = a.w + (int64_t)grp * MT * wrec + lane * 4 + kh * (2 * 256);
+    const float* wl = wbase + (int64_t)grp * MT * wrec + lane * 4 + kh * (2 * 256);
 
     auto chunk_src = [&](int cc, int i) -> const float* {         // source pointer of staging slot i for chunk cc
         int s = 0, c = cc;
         if (a.nsrc > 1 && cc >= a.src_chunks[0]) { s = 1; c = cc - a.src_chunks[0]; }
-        return a.src[s] + ((int64_t)b * plane + srcpix[i]) * a.src_stride[s] + a.src_off[s] + c * IFL_CK + q4;
+        return (s ? src1 : src0) + ((int64_t)b * plane + srcpix[i]) * a.src_stride[s] + a.src_off[s] + c * IFL_CK + q4;
     };
 
     f32x4 stage[LD_SLOTS];
@@ -156,8 +169,8 @@ void convg_kernel(IflConvArgs a)
         for (int gq = 0; gq < 4; ++gq) {
             const int c = cbase + m * 32 + gq * 8;
             f32x4 v = {tot[m][gq * 4], tot[m][gq * 4 + 1], tot[m][gq * 4 + 2], tot[m][gq * 4 + 3]};
-            if (a.bias) {
-                f32x4 bb = *(const f32x4*)(a.bias + c);
+            if (biasp) {
+                f32x4 bb = *(const f32x4*)(biasp + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + bb[e];
             }
@@ -168,8 +181,8 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
-            if (a.res1) {
-                f32x4 r = *(const f32x4*)(a.res1 + opix * a.res1_stride + a.res1_off + c);
+            if (res1p) {
+                f32x4 r = *(const f32x4*)(res1p + opix * a.res1_stride + a.res1_off + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = v[e] * a.alpha; v[e] = v[e] + r[e]; }
             }
@@ -178,7 +191,7 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = v[e] * a.beta; v[e] = v[e] + r[e]; }
             }
-            *(f32x4*)(a.out + opix * a.out_stride + a.out_off + c) = v;
+            *(f32x4*)(outp + opix * a.out_stride + a.out_off + c) = v;
         }
 }
 
@@ -190,20 +203,23 @@ int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st)
     IFL_CHECK_ARG(a.taps == 9 || a.taps == 1, IFL_EINVAL, "convg: taps=%d", a.taps);
     IFL_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2 && a.nchunks >= 1, IFL_EINVAL, "convg: sources");
     IFL_CHECK_ARG(a.g.tpx == IFL_MT, IFL_EINVAL, "convg: tiling of %d pixels per tile", a.g.tpx);
+    const int nz = a.nz > 1 ? a.nz : 1;
+    IFL_CHECK_ARG((int64_t)B * nz <= 65535 && (nz == 1 || a.Bz == B), IFL_EINVAL, "convg: %d images x %d problems exceed the grid", B, nz);
+    const int By = B * nz;                                        // grid.y: (problem, image)
     // fewer workgroups than 1.5 per CU even at 32 output channels each: 64-pixel tiles with the K loop split inside the
     // workgroup (same bits, see the kernel)
-    if ((int64_t)a.g.ntiles * B * (a.cout / 32) < 384) {
+    if ((int64_t)a.g.ntiles * By * (a.cout / 32) < 384) {
         IflConvArgs h = a;
         h.g = ifl_choose_geom(a.g.H, a.g.W, IFL_MT / 2);
-        dim3 grid(h.g.ntiles, B, a.cout / 32), block(256);
+        dim3 grid(h.g.ntiles, By, a.cout / 32), block(256);
         if (a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9, true>), grid, block, 0, st, h);
         else hipLaunchKernelGGL((convg_kernel<1, 1, true>), grid, block, 0, st, h);
         IFL_LAUNCH_CHECK();
         return 0;
     }
     // 64 output channels per workgroup when that still fills the chip, else 32 (twice the workgroups, half the latency each)
-    const int mt = (a.cout % 64 == 0 && (int64_t)a.g.ntiles * B * (a.cout / 64) >= 256) ? 2 : 1;
-    dim3 grid(a.g.ntiles, B, a.cout / (32 * mt)), block(256);
+    const int mt = (a.cout % 64 == 0 && (int64_t)a.g.ntiles * By * (a.cout / 64) >= 256) ? 2 : 1;
+    dim3 grid(a.g.ntiles, By, a.cout / (32 * mt)), block(256);
     if (mt == 2 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<2, 9, false>), grid, block, 0, st, a);
     else if (mt == 1 && a.taps == 9) hipLaunchKernelGGL((convg_kernel<1, 9, false>), grid, block, 0, st, a);
     else if (mt == 2) hipLaunchKernelGGL((convg_kernel<2, 1, false>), grid, block, 0, st, a);

@@ -167,6 +167,9 @@ struct IflConvArgs {
     const float* res1; int res1_stride, res1_off; float alpha;
     const float* res2; int res2_stride, res2_off; float beta;
     IflGeom g;
+    // batched form: nz independent problems of one shape in one launch (blockIdx.y = z * Bz + image), operands z_* floats apart
+    int nz, Bz;
+    int64_t z_src[2], z_w, z_bias, z_out, z_res1;
 };
 int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
 int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,

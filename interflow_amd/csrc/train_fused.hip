@@ -22,9 +22,11 @@
 #include "../../include/interflow_hip.h"
 #include <mutex>
 
-int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream);
+int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream,
+                      int nz = 1, int64_t xz = 0, int64_t yz = 0, int64_t pz = 0);
 int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
-                      int B, int h, int w, int C, hipStream_t stream);
+                      int B, int h, int w, int C, hipStream_t stream, int nz = 1, int64_t xz = 0, int64_t gz = 0, int64_t dxz = 0,
+                      int64_t pz = 0, int64_t partz = 0);
 int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, const float* h_ring, int hstride, const float* logs3,
                        float eps, int branch, int c0, int n, float* dz, float* dh_ring, float* dlogs_part, float* dbias_part, int B,
                        int h, int w, int C, hipStream_t stream);
@@ -358,6 +360,8 @@ int check_level(const ifl_train_level* L) {
                   "train level: B=%d h=%d w=%d C=%d (C 12 or 48)", L->B, L->h, L->w, L->C);
     IFL_CHECK_ARG(L->ch >= 1 && L->ch <= 32 && L->ch < L->C, IFL_ENOTSUP, "train level: %d of %d channels feed the coupling networks", L->ch, L->C);
     IFL_CHECK_ARG(L->branch == 0 || L->branch == 1, IFL_EINVAL, "branch %d", L->branch);
+    IFL_CHECK_ARG(!L->f_batched || (L->raw && L->skip_step_wgrad && L->anp && L->da_all && L->anp_step >= 256), IFL_EINVAL,
+                  "train level: f_batched needs raw, skip_step_wgrad, anp and da_all");
     for (int s = 0; s < L->nsteps; ++s) {
         const ifl_train_step& S = L->steps[s];
         IFL_CHECK_ARG(S.M && S.c && S.dM_part && S.z_in && S.z_a, IFL_EINVAL, "train step %d: null pointer", s);
@@ -380,7 +384,7 @@ int check_level(const ifl_train_level* L) {
     return 0;
 }
 
-static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 248 && sizeof(ifl_train_step) == 568 && sizeof(ifl_train_level) == 160,
+static_assert(sizeof(ifl_pack_desc) == 72 && sizeof(ifl_train_net) == 248 && sizeof(ifl_train_step) == 568 && sizeof(ifl_train_level) == 192,
               "the Python side (train_fused.py) mirrors these structs");
 
 }  // namespace
@@ -490,6 +494,11 @@ int fwd_step(const ifl_train_level* L, const Grp& G, int s, int cstep, hipStream
             const float* p1 = N.p1 + ro * N.p1_stride;
             float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
             const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
+            if (L->f_batched && !N.has_z1) {  // its network ran for all steps before the chain
+                IFL_TRY(ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
+                                         B, h, w, C, st));
+                continue;
+            }
             if (N.has_z1) {
                 float* z1 = (S.z1 ? S.z1 : L->z1ring) + ro * 32;
                 hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, z1, npx, h, w, C, L->ch);
@@ -544,6 +553,7 @@ int bwd_step(const ifl_train_level* L, const Grp& G, int s, const float** gp, co
                 const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
                 IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part + co,
                                            N.dbias_part + co, B, h, w, C, st));
+                if (L->f_batched && !N.has_z1) { g = dzn; continue; }     // its network's backward runs for all steps after the chain
                 // Conv2dZeros 3x3: a2 -> hraw
                 if (wg) IFL_TRY(ifl_conv2d_wgrad(a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
                 IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
@@ -613,11 +623,83 @@ int groups_end(Groups& R, int rc)
     return rc;
 }
 
+// The z-independent network of every conditional step (f_batched): strides between consecutive conditional steps, taken from
+// the first two step records and checked on the rest.
+struct FBatch { const ifl_train_net* N0; int nz; int64_t a1, p2, a2, hraw, w2, w3, bias3, w2t, w3t, dp1, dp2, dh, an1p, an2p; };
+
+int f_batch(const ifl_train_level* L, FBatch* out)
+{
+    FBatch F{};
+    const ifl_train_net* prev = nullptr;
+    for (int s = 0; s < L->nsteps; ++s) {
+        if (!L->steps[s].cond) continue;
+        const ifl_train_net* N = nullptr;
+        for (int i = 0; i < 2; ++i) if (!L->steps[s].net[i].has_z1) N = &L->steps[s].net[i];
+        IFL_CHECK_ARG(N && N->dp1 && N->dp2 && N->dh && N->p1_stride == 128, IFL_EINVAL, "f_batched: step %d has no z-independent network on the bulk slab", s);
+        if (!F.N0) F.N0 = N;
+        else {
+            const int64_t d[14] = {N->a1 - prev->a1, N->p2 - prev->p2, N->a2 - prev->a2, N->hraw - prev->hraw, N->w2 - prev->w2, N->w3 - prev->w3,
+                                   N->bias3 - prev->bias3, N->w2t - prev->w2t, N->w3t - prev->w3t, N->dp1 - prev->dp1, N->dp2 - prev->dp2,
+                                   N->dh - prev->dh, N->an1_part - prev->an1_part, N->an2_part - prev->an2_part};
+            int64_t* f = &F.a1;
+            for (int k = 0; k < 14; ++k) {
+                if (F.nz == 1) f[k] = d[k];
+                IFL_CHECK_ARG(f[k] == d[k] && d[k] % 4 == 0, IFL_EINVAL, "f_batched: buffer %d of step %d is not at the common stride", k, s);
+            }
+            IFL_CHECK_ARG(N->hstride == F.N0->hstride && N->p1 - prev->p1 == L->raw_step, IFL_EINVAL, "f_batched: step %d differs in shape", s);
+        }
+        prev = N;
+        ++F.nz;
+    }
+    IFL_CHECK_ARG(F.nz >= 1 && (int64_t)F.nz * L->B <= 65535, IFL_EINVAL, "f_batched: %d steps", F.nz);
+    *out = F;
+    return 0;
+}
+
+int conv_b(const float* src, int c, int64_t src_z, const float* w, int64_t w_z, const float* bias, int64_t bias_z, float* out, int cout,
+           int64_t out_z, int taps, int nz, int B, int h, int w_, hipStream_t st)
+{
+    ifl_conv_desc d = {};
+    d.src[0] = src; d.src_stride[0] = c; d.src_ch[0] = c; d.nsrc = 1;
+    d.w = w; d.bias = bias; d.out = out; d.out_stride = cout; d.cout = cout; d.taps = taps;
+    d.alpha = d.beta = 1.f;
+    if (nz == 1) return ifl_conv2d(&d, B, h, w_, st);
+    return ifl_conv2d_batched(&d, nz, src_z, 0, w_z, bias_z, out_z, 0, B, h, w_, st);
+}
+
+int f_forward(const ifl_train_level* L, hipStream_t st)
+{
+    FBatch F;
+    IFL_TRY(f_batch(L, &F));
+    const ifl_train_net& N = *F.N0;
+    const int B = L->B, h = L->h, w = L->w;
+    IFL_TRY(ifl_k_an_relu_fwd(N.p1, 128, N.a1, L->anp, L->anp + 64, B, h, w, 64, st, F.nz, L->raw_step, F.a1, L->anp_step));
+    IFL_TRY(conv_b(N.a1, 64, F.a1, N.w2, F.w2, nullptr, 0, N.p2, 64, F.p2, 1, F.nz, B, h, w, st));
+    IFL_TRY(ifl_k_an_relu_fwd(N.p2, 64, N.a2, L->anp + 128, L->anp + 192, B, h, w, 64, st, F.nz, F.p2, F.a2, L->anp_step));
+    return conv_b(N.a2, 64, F.a2, N.w3, F.w3, N.bias3, F.bias3, N.hraw, N.hstride, F.hraw, 9, F.nz, B, h, w, st);
+}
+
+int f_backward(const ifl_train_level* L, hipStream_t st)
+{
+    FBatch F;
+    IFL_TRY(f_batch(L, &F));
+    const ifl_train_net& N = *F.N0;
+    const int B = L->B, h = L->h, w = L->w;
+    const int64_t da_z = (int64_t)B * (h + 2) * (w + 2) * 64;
+    IFL_TRY(conv_b(N.dh, N.hstride, F.dh, N.w3t, F.w3t, nullptr, 0, L->da_all, 64, da_z, 9, F.nz, B, h, w, st));
+    IFL_TRY(ifl_k_an_relu_bwd(N.p2, 64, L->da_all, N.dp2, L->anp + 128, L->anp + 192, N.an2_part, B, h, w, 64, st, F.nz, F.p2, da_z, F.dp2,
+                              L->anp_step, F.an2p));
+    IFL_TRY(conv_b(N.dp2, 64, F.dp2, N.w2t, F.w2t, nullptr, 0, L->da_all, 64, da_z, 1, F.nz, B, h, w, st));
+    return ifl_k_an_relu_bwd(N.p1, 128, L->da_all, N.dp1, L->anp, L->anp + 64, N.an1_part, B, h, w, 64, st, F.nz, L->raw_step, da_z, F.dp1,
+                             L->anp_step, F.an1p);
+}
+
 }  // namespace
 
 extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
 {
     IFL_TRY(check_level(L));
+    if (L->f_batched) IFL_TRY(f_forward(L, (hipStream_t)stream));
     Groups R;
     IFL_TRY(groups_begin(L, (hipStream_t)stream, &R));
     int rc = 0, cstep = -1;
@@ -639,5 +721,7 @@ extern "C" int ifl_train_level_bwd(const ifl_train_level* L, const float* dz_out
     int rc = 0;
     for (int s = L->nsteps - 1; s >= 0 && !rc; --s)
         for (int k = 0; k < R.n && !rc; ++k) rc = bwd_step(L, R.g[k], s, &gp[k], dld, dz_in, R.st[k]);
-    return groups_end(R, rc);
+    rc = groups_end(R, rc);
+    if (!rc && L->f_batched) rc = f_backward(L, (hipStream_t)stream);
+    return rc;
 }

@@ -27,8 +27,9 @@ __device__ __forceinline__ int64_t ring_px(int64_t p, int h, int w) {
 // x, y ringed [B][h+2][w+2][C], C = 64 (x may be a 64-channel range of a wider buffer: pixel stride xs): thread = (pixel lane, channel quad)
 __global__ __launch_bounds__(256)
 void an_relu_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__ y, const float* __restrict__ bias,
-                        const float* __restrict__ logs, int64_t npx, int h, int w, int C)
+                        const float* __restrict__ logs, int64_t npx, int h, int w, int C, int64_t xz, int64_t yz, int64_t pz)
 {
+    x += blockIdx.y * xz; y += blockIdx.y * yz; bias += blockIdx.y * pz; logs += blockIdx.y * pz;     // batched: problem blockIdx.y
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const f32x4 b = *(const f32x4*)(bias + cq * 4);
     f32x4 s = *(const f32x4*)(logs + cq * 4);
@@ -47,8 +48,10 @@ void an_relu_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__
 __global__ __launch_bounds__(256)
 void an_relu_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, float* __restrict__ dx,
                         const float* __restrict__ bias, const float* __restrict__ logs, float* __restrict__ part,
-                        int64_t npx, int h, int w, int C)
+                        int64_t npx, int h, int w, int C, int64_t xz, int64_t gz, int64_t dxz, int64_t pz, int64_t partz)
 {
+    x += blockIdx.y * xz; dy += blockIdx.y * gz; dx += blockIdx.y * dxz; bias += blockIdx.y * pz; logs += blockIdx.y * pz;
+    part += blockIdx.y * partz;
     __shared__ float red[16][2][64];
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const f32x4 b = *(const f32x4*)(bias + cq * 4);
@@ -186,31 +189,34 @@ void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ 
 
 extern "C" int64_t ifl_an_relu_blocks(int B, int h, int w) { return ((int64_t)B * h * w + GPX - 1) / GPX; }
 
-int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream)
+int ifl_k_an_relu_fwd(const float* x, int xs, float* y, const float* bias, const float* logs, int B, int h, int w, int C, hipStream_t stream,
+                      int nz, int64_t xz, int64_t yz, int64_t pz)
 {
+    IFL_CHECK_ARG(nz >= 1 && nz <= 65535, IFL_EINVAL, "an_relu: %d problems", nz);
     IFL_CHECK_ARG(x && y && bias && logs && xs >= C && xs % 4 == 0, IFL_EINVAL, "null pointer / stride");
     IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
     IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
     const int64_t npx = (int64_t)B * h * w;
-    hipLaunchKernelGGL(an_relu_fwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, stream, x, xs, y, bias, logs, npx, h, w, C);
+    hipLaunchKernelGGL(an_relu_fwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w), nz), dim3(256), 0, stream, x, xs, y, bias, logs, npx, h, w, C, xz, yz, pz);
     IFL_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int ifl_an_relu_fwd(const float* x, float* y, const float* bias, const float* logs, int B, int h, int w, int C, void* stream)
 {
-    return ifl_k_an_relu_fwd(x, C, y, bias, logs, B, h, w, C, (hipStream_t)stream);
+    return ifl_k_an_relu_fwd(x, C, y, bias, logs, B, h, w, C, (hipStream_t)stream, 1, 0, 0, 0);
 }
 
 int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
-                      int B, int h, int w, int C, hipStream_t stream)
+                      int B, int h, int w, int C, hipStream_t stream, int nz, int64_t xz, int64_t gz, int64_t dxz, int64_t pz, int64_t partz)
 {
+    IFL_CHECK_ARG(nz >= 1 && nz <= 65535, IFL_EINVAL, "an_relu: %d problems", nz);
     IFL_CHECK_ARG(x && dy && dx && bias && logs && partials && xs >= C && xs % 4 == 0, IFL_EINVAL, "null pointer / stride");
     IFL_CHECK_ARG(C == 64, IFL_ENOTSUP, "an_relu: C=%d (the coupling networks' hidden width is 64)", C);
     IFL_CHECK_ARG(B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "bad shape");
     const int64_t npx = (int64_t)B * h * w;
-    hipLaunchKernelGGL(an_relu_bwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w)), dim3(256), 0, stream, x, xs, dy, dx, bias, logs,
-                       partials, npx, h, w, C);
+    hipLaunchKernelGGL(an_relu_bwd_kernel, dim3((unsigned)ifl_an_relu_blocks(B, h, w), nz), dim3(256), 0, stream, x, xs, dy, dx, bias, logs,
+                       partials, npx, h, w, C, xz, gz, dxz, pz, partz);
     IFL_LAUNCH_CHECK();
     return 0;
 }
@@ -218,7 +224,7 @@ int ifl_k_an_relu_bwd(const float* x, int xs, const float* dy, float* dx, const 
 extern "C" int ifl_an_relu_bwd(const float* x, const float* dy, float* dx, const float* bias, const float* logs, float* partials,
                                int B, int h, int w, int C, void* stream)
 {
-    return ifl_k_an_relu_bwd(x, C, dy, dx, bias, logs, partials, B, h, w, C, (hipStream_t)stream);
+    return ifl_k_an_relu_bwd(x, C, dy, dx, bias, logs, partials, B, h, w, C, (hipStream_t)stream, 1, 0, 0, 0, 0, 0);
 }
 
 extern "C" int ifl_coupling_blocks(int h, int w) { return (h * w + CPX - 1) / CPX; }

@@ -88,10 +88,11 @@ class IflTrainLevel(Structure):
     _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch", "skip_step_wgrad", "groups")] + \
                [("eps", c_float), ("skip_ft_wgrad", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
                 ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
+                ("anp", c_void_p), ("anp_step", c_int64), ("da_all", c_void_p), ("f_batched", c_int32), ("pad3_", c_int32),
                 ("raw", c_void_p), ("raw_step", c_int64)]
 
 
-assert ctypes.sizeof(IflTrainNet) == 248 and ctypes.sizeof(IflTrainStep) == 568 and ctypes.sizeof(IflTrainLevel) == 160
+assert ctypes.sizeof(IflTrainNet) == 248 and ctypes.sizeof(IflTrainStep) == 568 and ctypes.sizeof(IflTrainLevel) == 192
 
 
 PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode", "<i4"), ("cout_real", "<i4"),
@@ -115,6 +116,10 @@ BATCHED_WGRAD = True
 # Samples are independent and the per-step chain is latency-bound at batch 8: the level drivers run the two halves of the
 # batch as two concurrent chains (ifl_train_level.groups).
 GROUPS = int(os.environ.get("IFL_TRAIN_GROUPS", "2"))
+# fFeatures sees only the conditioning: with USE_BULK and BATCHED_WGRAD its ActNorm+ReLU / 1x1 / last convolution run as ONE
+# launch each for all 16 steps of a level, before the chain (forward) and after it (backward), and the sequential chain
+# only applies its coupling (ifl_train_level.f_batched).
+F_BATCHED = os.environ.get("IFL_TRAIN_F_BATCHED", "1") != "0"
 WDST_DTYPE = np.dtype([("dst", "<u8"), ("cin", "<i4"), ("zoff", "<i4")])
 
 _bound = False
@@ -161,7 +166,7 @@ def _net_params(seq):
 class LevelPlan:
     """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
 
-    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True, batched=True):
+    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True, batched=True, f_batched=True):
         L = _lib()
         self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
         self.busy = False
@@ -195,7 +200,9 @@ class LevelPlan:
         self.act = zeros(max(nc, 1), 2, 4, B, h + 2, w + 2, 64)        # p1, a1, p2, a2 per (step, network)
         self.hraw = [zeros(max(nc, 1), B, h + 2, w + 2, hs) for hs in self.hstride]
         self.an_part = zeros(max(nc, 1), 2, 2, nblk_an, 128)
+        self.an_sum = zeros(max(nc, 1), 2, 2, 128)                     # the partial sums added up (persistent: gradient views below)
         self.cpl_part = [zeros(max(nc, 1), 2, B * nblk_c, 2 * n) for _, _, n, _ in self.nets]      # (d logs3 | d bias3)
+        self.cpl_sum = [zeros(max(nc, 1), 2, 2 * n) for _, _, n, _ in self.nets]
         self.ldpart = zeros(max(nc, 1), 2, B, nblk_c)
         # packed weights / dense gradients / parameter-layout gradients: one flat buffer each
         sizes_w, sizes_g, sizes_r = [], [], []
@@ -222,6 +229,10 @@ class LevelPlan:
             self.dp2 = zeros(nc * 2, B, h + 2, w + 2, 64)
             self.dh_all = [zeros(nc, B, h + 2, w + 2, hs) for hs in self.hstride]
             self.z1_all = zeros(nc, B, h + 2, w + 2, 32)
+        self.f_batched = bool(f_batched) and self.bulk and self.batched
+        if self.f_batched:
+            self.anp = zeros(nc, 256)                                    # fFeatures' ActNorm parameters per step (an1 b | l | an2 b | l)
+            self.da_all = zeros(nc, B, h + 2, w + 2, 64)
         if self.wino_wgrad:
             K = int(L.ifl_wino4_tiles(B, h, w))
             self.Vt = zeros(36, N_RRDB_CH, K)
@@ -316,6 +327,10 @@ class LevelPlan:
                               dict(src=ptr(b3), dst=ptr(wv[6]), nelem=hs, mode=PACK_VECTOR, cout_real=2 * n, cout_pad=hs, taps=1)]
                 if z1:
                     pack_rows.append(dict(src=ptr(w1), dst=ptr(wv[3]), nelem=wv[3].numel(), mode=PACK_TRANSPOSED, a0=0, acnt=32, **common1))
+                elif self.f_batched:
+                    for k, prm_ in enumerate((an1b, an1l, an2b, an2l)):
+                        pack_rows.append(dict(src=ptr(prm_), dst=ptr(self.anp[ci, k * 64:(k + 1) * 64]), nelem=64, mode=PACK_VECTOR,
+                                              cout_real=64, cout_pad=64, taps=1))
                 roffs = np.cumsum([0] + sizes_r[i])
                 rv = [self.graw[ro + roffs[k]: ro + roffs[k + 1]] for k in range(3)]
                 ro += int(roffs[-1])
@@ -327,6 +342,18 @@ class LevelPlan:
                                       ("w", rv[1], w2.shape), ("an", (ci, i, 1, 0), an2b.shape), ("an", (ci, i, 1, 1), an2l.shape),
                                       ("w", rv[2], w3.shape), ("cpl", (i, ci, 1), b3.shape), ("cpl", (i, ci, 0), l3.shape)]
             ci += 1
+        # the gradient of every parameter as a view of the persistent buffers, in the order of self.params
+        self.grad_views = []
+        for kind, where, shape in self.param_slices:
+            if kind == "w":
+                self.grad_views.append(where.view(shape))
+            elif kind == "an":
+                s_, i_, a_, k_ = where
+                self.grad_views.append(self.an_sum[s_, i_, a_, k_ * 64:(k_ + 1) * 64].reshape(shape))
+            else:
+                i_, s_, k_ = where
+                self.grad_views.append(self.cpl_sum[i_][s_, k_].reshape(shape))
+        assert all(v.data_ptr() != 0 and v._base is not None for v in self.grad_views)
         assert zi == self.z.shape[0] - 1
         self.z_first, self.z_last = self.z[0], self.z[zi]
         self.param_ptrs = tuple(p.data_ptr() for p in self.params)
@@ -357,6 +384,8 @@ class LevelPlan:
             lv.raw, lv.raw_step = ptr(self.raw), self.raw[0].numel()
         if self.batched:
             lv.skip_step_wgrad = 1
+        if self.f_batched:
+            lv.f_batched, lv.anp, lv.anp_step, lv.da_all = 1, ptr(self.anp), 256, ptr(self.da_all)
         if self.wino_wgrad:
             lv.skip_ft_wgrad = 1
             arr = np.zeros(len(wdst_rows), dtype=WDST_DTYPE)
@@ -480,27 +509,13 @@ class _LevelFn(torch.autograd.Function):
                                          plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
             torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
             hip.check(L.ifl_wino4_dw(hip._ptr(plan.dU), rows, hip._ptr(plan.wdst), plan.dp1.shape[0], hip._stream()), "ifl_wino4_dw")
-        an = plan.an_part.sum(dim=3)                                   # [cond steps, network, actnorm, 128]
-        cpl = [t.sum(dim=2) for t in plan.cpl_part]                    # per network slot: [cond steps, (logs3 | bias3), 2n]
-        grads, dst, src = [], [], []
-        for (kind, where, shape), p in zip(plan.param_slices, plan.params):
-            if kind == "w":
-                g = where.view(shape)
-            elif kind == "an":
-                s, i, a, k = where
-                g = an[s, i, a, k * 64:(k + 1) * 64].reshape(shape)
-            else:
-                i, s, k = where
-                g = cpl[i][s, k].reshape(shape)
-            if direct:
-                dst.append(p.grad)
-                src.append(g)
-                grads.append(None)
-            else:
-                grads.append(g.clone() if kind == "w" else g)
-        if dst:
-            torch._foreach_add_(dst, src)
-        return grads
+        torch.sum(plan.an_part, dim=3, out=plan.an_sum)               # [cond steps, network, actnorm, 128]
+        for t, o in zip(plan.cpl_part, plan.cpl_sum):                  # per network slot: [cond steps, (logs3 | bias3), 2n]
+            torch.sum(t, dim=2, out=o)
+        if direct:
+            torch._foreach_add_([p.grad for p in plan.params], plan.grad_views)
+            return [None] * len(plan.params)
+        return [g.clone() for g in plan.grad_views]
 
 
 def _affine_maps(steps, C, pixels):
@@ -544,7 +559,7 @@ def usable(fu, feats) -> bool:
 
 def _plan_for(fu, level, steps, B, h, w, C, device, params):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device), GROUPS, BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
+    key = (level, B, h, w, C, str(device), F_BATCHED, GROUPS, BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:
@@ -552,7 +567,7 @@ def _plan_for(fu, level, steps, B, h, w, C, device, params):
             return p
     if len(plans) >= MAX_PLANS_PER_SHAPE:
         return None
-    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD, batched=BATCHED_WGRAD)
+    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD, batched=BATCHED_WGRAD, f_batched=F_BATCHED)
     plans.append(p)
     return p
 
@@ -574,7 +589,10 @@ def run_encode(fu, src, feats, ld):
     h, w = z.shape[1], z.shape[2]
     for lv, (C, steps) in enumerate(levels, start=1):
         h, w = h // 2, w // 2
-        params = [p for s in steps if hasattr(s, "affine") for name in ("fAffine", "fFeatures") for p in _net_params(getattr(s.affine, name))]
+        pcache = fu.__dict__.setdefault("_train_params", {})
+        if lv not in pcache:                      # the modules (and their Parameter objects) are fixed after construction
+            pcache[lv] = [p for s in steps if hasattr(s, "affine") for name in ("fAffine", "fFeatures") for p in _net_params(getattr(s.affine, name))]
+        params = pcache[lv]
         plan = _plan_for(fu, lv, steps, B, h, w, C, src.device, params)
         if plan is None:
             return None

@@ -54,15 +54,18 @@ class GradientAllReducer:
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
         self.buckets.append({"params": list(plist), "flat": flat, "pending": 0, "work": None, "launched": False})
 
-    def zero_grad(self):
-        """Zero the buckets and (re)attach every parameter's .grad as a view into its bucket."""
+    def zero_grad(self, reattach: bool = False):
+        """Zero the buckets; attach every parameter's .grad as a view into its bucket (once: autograd accumulates into an
+        existing .grad in place, and `_on_grad` brings back a tensor that was replaced; `reattach` forces it again)."""
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
-            o = 0
-            for p in b["params"]:
-                p.grad = b["flat"][o:o + p.numel()].view_as(p)
-                o += p.numel()
+            if reattach or not b.get("attached") or any(p.grad is None for p in b["params"]):
+                o = 0
+                for p in b["params"]:
+                    p.grad = b["flat"][o:o + p.numel()].view_as(p)
+                    o += p.numel()
+                b["attached"] = True
 
     def _launch(self, b):
         b["launched"] = True
@@ -121,7 +124,11 @@ def _uninitialised_actnorms(model):
     and the bias all zero; a module with a non-zero bias is marked initialised, as the reference does).  One device
     synchronisation for all candidates, none once every module is marked."""
     from .flow_modules import ActNorm2d
-    cands = [m for m in model.modules() if isinstance(m, ActNorm2d) and m.training and not m.inited]
+    acts = model.__dict__.get("_ifl_actnorms")                    # the module list is fixed after construction
+    if acts is None:
+        acts = [m for m in model.modules() if isinstance(m, ActNorm2d)]
+        model.__dict__["_ifl_actnorms"] = acts
+    cands = [m for m in acts if not m.inited and m.training]
     if not cands:
         return []
     nonzero = torch.stack([(m.bias != 0).any() for m in cands]).cpu().tolist()

@@ -182,9 +182,10 @@ def test_fused_level_training_vs_oracle():
         assert rel(named[k].grad, g) < 2e-4, k
     # the level drivers with every first convolution in the direct form (no Winograd bulk launch), with the Winograd forward
     # but the direct weight-gradient kernel, with one weight-gradient launch per step instead of the batched ones, and with
-    # one chain per level instead of two concurrent sample groups
+    # one chain per level instead of two concurrent sample groups, and with fFeatures' network inside the chain
     from interflow_amd import train_fused
-    for attr, off, on in (("USE_BULK", False, True), ("WINO_WGRAD", False, True), ("BATCHED_WGRAD", False, True), ("GROUPS", 1, 2)):
+    for attr, off, on in (("USE_BULK", False, True), ("WINO_WGRAD", False, True), ("BATCHED_WGRAD", False, True), ("GROUPS", 1, 2),
+                          ("F_BATCHED", False, True)):
         setattr(train_fused, attr, off)
         try:
             z4, nll4, ld4, _, loss4 = step()
