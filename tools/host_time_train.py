@@ -1,3 +1,5 @@
+"""Host-side issue time of the phases of one training step (no device synchronisation inside a step): shows whether the step
+is bound by the host issuing launches or by the device (the wait at the end).  python tools/host_time_train.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interflow_amd import synth, training, train_fused
