@@ -231,6 +231,31 @@ def run(fu, src, rrdbResults, logdet, test_input_size, decode):
 LOG2PI = 1.8378770664093453
 
 
+class _InvLogdet(torch.autograd.Function):
+    """(cov^-1, log|det cov|) of the 48x48 class covariance with a hand-written backward.  torch.inverse and the backward
+    pass of torch.slogdet read an error flag on the host: a device synchronisation per class in the forward pass and another
+    at the very start of the backward pass, where the host then waits for the whole forward to drain before it can issue
+    anything else.  inv_ex / slogdet's forward do not; the gradients are  d cov = -inv^T d_inv inv^T + d_logdet inv^T.
+    A singular covariance gives inf/nan (the reference raises); the training step's loss guard then drops the update."""
+
+    @staticmethod
+    def forward(ctx, cov):
+        inv = torch.linalg.inv_ex(cov)[0]
+        ctx.save_for_backward(inv)
+        return inv, torch.linalg.slogdet(cov)[1]
+
+    @staticmethod
+    def backward(ctx, g_inv, g_ld):
+        inv, = ctx.saved_tensors
+        it = inv.transpose(-1, -2)
+        g = torch.zeros_like(inv)
+        if g_inv is not None:
+            g = g - torch.matmul(it, torch.matmul(g_inv, it))
+        if g_ld is not None:
+            g = g + g_ld[..., None, None] * it
+        return g
+
+
 def gaussian_logp(mean, cov, x):
     """Gaussian.logp / likelihood, flow.py:138-161, differentiable (x is NCHW)."""
     if mean is None and cov is None:
@@ -238,8 +263,6 @@ def gaussian_logp(mean, cov, x):
     x_ = x.permute(0, 2, 3, 1)
     x_c = x_ - mean
     k = x.shape[1]
-    cov_inv = torch.linalg.inv_ex(cov)[0]      # torch.inverse without its host-side error check (a device synchronisation);
-    #                                            a singular covariance gives inf/nan here and the step's loss guard drops the update
-    logdet = torch.slogdet(cov)[1]
+    cov_inv, logdet = _InvLogdet.apply(cov)    # flow.py:146-149's torch.inverse / torch.slogdet without their host round trips
     lik = -0.5 * (logdet + k * LOG2PI + (torch.matmul(x_c, cov_inv) * x_c).sum(dim=3))
     return lik.sum(dim=(1, 2))
