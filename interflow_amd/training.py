@@ -204,7 +204,7 @@ def consistency_loss(model, gt, lr_enc, low_res, img_lr1, scale1, img_lr2, scale
     return torch.nn.functional.l1_loss(synth_down, interp_down).mean()                  # :104-106
 
 
-def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, device):
+def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, device, host_sync=True):
     """train_step's tail with the skip guards after the backward pass (see `late_check`)."""
     from .train_fused import accumulate_into_grad
     dist = reducer.dist if reducer is not None else None
@@ -219,6 +219,28 @@ def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_
     finally:
         if reducer is not None:
             reducer.defer = False
+    if not host_sync:
+        # No host read at all: the guards are evaluated on the device and handed to the fused optimizer as its `found_inf`
+        # flag (the mechanism torch's GradScaler uses: the update kernel leaves parameters, moments and step counters
+        # untouched when it is set), so the host can go on issuing the next step while this one still runs.
+        if not getattr(optimizer, "_step_supports_amp_scaling", False):
+            raise RuntimeError("train_step(host_sync=False) needs an optimizer that takes a device-side skip flag (Adam(fused=True))")
+        l = loss.detach()
+        flag = (~torch.isfinite(l)) | ((l > 30) if step > 100 else torch.zeros_like(l, dtype=torch.bool))   # train.py:113-126
+        flag = flag.to(torch.float32).reshape(())
+        if dist is not None and dist.get_world_size() > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # collective decision, on the device
+        if reducer is not None:
+            reducer.finish()
+        optimizer.found_inf = flag
+        try:
+            optimizer.step()                                                            # :130 (skipped on the device when flag = 1)
+        finally:
+            del optimizer.found_inf
+        if scheduler is not None:
+            scheduler.step()                                  # every iteration: the host does not know about a skip
+        out.update(skipped=flag, loss=l, nll=nll_loss.detach(), ib_loss=ib_loss.detach(), consistency_loss=cons.detach())
+        return out
     terms = torch.stack([loss.detach(), nll_loss.detach(), ib_loss.detach(), cons.detach()]).tolist()    # the step's one host read
     bad = (terms[0] != terms[0] or abs(terms[0]) == float("inf")) or (step > 100 and terms[0] > 30)     # :113-126
     if dist is not None and dist.get_world_size() > 1:
@@ -280,14 +302,17 @@ class EncoderPrefetcher:
 
 def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, reducer: Optional[GradientAllReducer] = None,
                scheduler=None, step: int = 0, add_gt_noise: bool = True, consistency_lambda: float = 0.0, interp=None,
-               interpolate_weight=None, lr_enc=None, late_check: bool = False):
+               interpolate_weight=None, lr_enc=None, late_check: bool = False, host_sync: bool = True):
     """One iteration of train.py:66-131.  interp = (img_lr1, scale1, img_lr2, scale2) enables the LR-consistency term
     (weight consistency_lambda; train.py's default is 10).  lr_enc: the conditioning features of `gt` when the caller has
     them already (`EncoderPrefetcher`).  late_check: evaluate the reference's skip guards AFTER the backward pass instead of
     before it (train.py:113-126 reads the loss on the host first): the step then has no device synchronisation between the
     forward and the backward pass, so the host issues the backward while the forward still runs; a skipped step has then
     computed gradients that nobody applies, and in data-parallel runs the all-reduce is launched only after the collective
-    decision (no overlap with the backward, and never fed with a skipped step's gradients).  Returns a dict of python floats (this synchronises, as the
+    decision (no overlap with the backward, and never fed with a skipped step's gradients).  host_sync=False (with
+    late_check): no host read at all -- the guards are evaluated on the device and passed to the fused optimizer as its
+    skip flag, the returned dict holds 0-dim device tensors (read them when a log line is due), and the scheduler is stepped
+    every iteration (the reference does not step it on a skipped one).  Returns a dict of python floats (this synchronises, as the
     reference's progress bar does at train.py:133-134) and `skipped`.
 
     Data parallel (reducer given): uninitialised ActNorms are initialised and broadcast first (`init_actnorm`), and the
@@ -314,7 +339,7 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
     loss = nll_loss + consistency_lambda * cons + ib_lambda * ib_loss                   # :110
     out = {"skipped": False}
     if late_check:
-        return _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, gt.device)
+        return _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_loss, cons, out, gt.device, host_sync)
     bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss.detach()) > 30)         # :113-126
     if dist is not None and dist.get_world_size() > 1:
         flag = torch.tensor([1.0 if bad else 0.0], device=gt.device)

@@ -407,6 +407,56 @@ def test_train_step_harness_learns():
     assert not moved["degradation_net.net.0.weight"] and not moved["arch.RRDB.conv_last.weight"]
 
 
+def test_train_step_modes_agree_and_device_side_guard_skips():
+    """train_step's three orders of the loss guards -- before the backward pass (reference order), after it, and on the device
+    with no host read (`host_sync=False`: the flag goes to the fused optimizer) -- give the same parameters after three steps
+    (frozen encoder, prefetched features: the path of the fast training configuration); a batch that makes the loss NaN
+    leaves parameters and Adam's state untouched in the device-side mode and is reported as skipped."""
+    from interflow_amd import training
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 2, 32
+    gt = torch.from_numpy(synth.synth_images(91, B, H, H)).to(dev())
+    lr = torch.from_numpy(synth.synth_images(92, B, H, H)).to(dev())
+    labels = torch.tensor([2, 4], device=dev())
+    results = []
+    for mode in (dict(), dict(late_check=True), dict(late_check=True, host_sync=False)):
+        model = InterpFlow(SCALES)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        model.train().to(dev())
+        model.arch.set_rrdb_training(False)
+        opt, sched = training.make_optimizer(model, lr=1e-4)
+        red = training.GradientAllReducer(model.parameters(), None)
+        pf = training.EncoderPrefetcher(model)
+        pf.submit(gt)
+        for it in range(3):
+            feats = pf.get()
+            pf.submit(gt)
+            out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, step=it, add_gt_noise=False,
+                                      lr_enc=feats, **mode)
+            assert not bool(out["skipped"]) and np.isfinite(float(out["loss"])), (mode, it, out)
+        results.append(({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}, float(out["loss"])))
+    for params, loss in results[1:]:
+        assert abs(loss - results[0][1]) < 1e-4 * abs(results[0][1])
+        # same arithmetic in the three orders; the weight gradients are accumulated with float atomics, and Adam turns a
+        # gradient that is rounding noise into an update of full size +-lr: parameters may differ by a few lr, no more
+        worst = max(float((params[k] - results[0][0][k]).abs().max()) for k in params)
+        assert worst <= 2 * 3 * 1e-4, worst
+    # model / opt / red are the device-side mode's: a NaN batch
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    steps_before = [float(st["step"]) for st in opt.state.values()]
+    bad_lr = lr.clone()                                  # the image that goes through the flow (gt only conditions it)
+    bad_lr[0, 0, 0, 0] = float("nan")
+    out = training.train_step(model, opt, gt, bad_lr, labels, reducer=red, scheduler=sched, step=3, add_gt_noise=False,
+                              lr_enc=pf.get(), late_check=True, host_sync=False)
+    assert bool(out["skipped"]) and not np.isfinite(float(out["loss"]))
+    assert all(torch.equal(v, before[k]) for k, v in model.named_parameters())
+    assert [float(st["step"]) for st in opt.state.values()] == steps_before
+    out = training.train_step(model, opt, gt, lr, labels, reducer=red, scheduler=sched, step=4, add_gt_noise=False,
+                              late_check=True, host_sync=False)
+    assert not bool(out["skipped"]) and np.isfinite(float(out["loss"]))
+    assert not torch.equal(dict(model.named_parameters())["mean_shift_0"], before["mean_shift_0"])
+
+
 def test_encoder_gradients_vs_oracle():
     """The conditioning encoder with autograd (RRDBNet on the differentiable HIP convolution): values of every key and
     the gradients of all its parameters against CPU autograd of the oracle."""

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--consistency", action="store_true", help="add the LR-consistency term (train.py's default lambda 10)")
     ap.add_argument("--prefetch-encoder", action="store_true",
                     help="with --frozen-rrdb: the encoder pass of the next batch on its own stream, overlapping this step (training.EncoderPrefetcher)")
+    ap.add_argument("--no-host-sync", action="store_true",
+                    help="train_step(late_check=True, host_sync=False): guards on the device, no host read inside a step")
     ap.add_argument("--late-check", action="store_true", help="train_step(late_check=True): no host read of the loss before the backward pass")
     ap.add_argument("--frozen-rrdb", action="store_true", help="do not train the conditioning encoder (no gradient wrt ft)")
     args = ap.parse_args()
@@ -56,6 +58,8 @@ def main():
                                                    torch.rand(B, 3, P, P, device=dev, generator=g), 4))
     if args.late_check:
         kw["late_check"] = True
+    if args.no_host_sync:
+        kw.update(late_check=True, host_sync=False)
     if args.prefetch_encoder:
         assert args.frozen_rrdb, "--prefetch-encoder needs --frozen-rrdb"
         training.init_actnorm(model, gt, lr, dist)
@@ -88,12 +92,15 @@ def main():
     loss = nll.mean() - ll_ib.mean()
     red.zero_grad(); loss.backward(); red.finish(); t.append(sync())
     opt.step(); t.append(sync())
+    out = {k: (float(v) if isinstance(v, torch.Tensor) and k != "skipped" else bool(v) if isinstance(v, torch.Tensor) else v)
+           for k, v in out.items()}
     ranks = shard.rank_devices(dist, dev)
     if rank == 0:
         print(json.dumps({"workload": f"training step (NLL + ib; forward, backward, Adam), batch {B} of {P}x{P} per GPU, fp32, "
                                       f"{'encoder frozen' if args.frozen_rrdb else 'encoder trained'}{', with LR-consistency term' if args.consistency else ''}"
                                       f"{', encoder pass of the next batch overlapped on a second stream' if args.prefetch_encoder else ''}"
-                                      f"{', loss guards after the backward pass' if args.late_check else ''}",
+                                      f"{', loss guards after the backward pass' if args.late_check else ''}"
+                                      f"{', loss guards on the device (no host read inside a step)' if args.no_host_sync else ''}",
                           "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
                           "ranks": ranks, "global_batch": B * world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                           "patches_per_s": B * world * args.steps / dt, "last": out,
