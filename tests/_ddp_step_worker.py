@@ -33,9 +33,14 @@ class Stub(torch.nn.Module):
         nll = z.square().mean(dim=(1, 2, 3))
         return z, nll, z.new_zeros(z.shape[0]), -0.1 * z.abs().mean(dim=(1, 2, 3))
 
+    def loss_terms(self, z, logdet, pixels, label):                    # (nll per sample, ib loss): train_step's late_check path
+        return z.square().mean(dim=(1, 2, 3)), (0.1 * z.abs().mean(dim=(1, 2, 3))).mean()
+
 
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
+    late = mode.endswith("_late")                                      # guards after the backward pass, all-reduce after the decision
+    mode = mode.replace("_late", "")
     rank, _, world = shard.dist_env()
     dist = shard.init_dist("gloo")
     torch.set_num_threads(1)
@@ -56,7 +61,7 @@ def main():
                 x = x * 1e3                                            # one rank's loss is > 30
         if it == 2:
             snap = [p.detach().clone() for p in model.parameters()]
-        out = training.train_step(model, opt, x, x, [2] * 4, reducer=red, step=step, add_gt_noise=False)
+        out = training.train_step(model, opt, x, x, [2] * 4, reducer=red, step=step, add_gt_noise=False, late_check=late)
         log.append(out["skipped"])
         if it == 2 and mode in ("nan", "large"):
             assert out["skipped"], (rank, out)                         # every rank skips, also the ones whose loss was fine

@@ -37,11 +37,12 @@ def test_gradient_allreduce_and_broadcast_two_ranks(tmp_path):
 import pytest
 
 
-@pytest.mark.parametrize("mode", ["plain", "nan", "large"])
+@pytest.mark.parametrize("mode", ["plain", "nan", "large", "plain_late", "nan_late", "large_late"])
 def test_train_step_two_ranks_init_broadcast_and_collective_skip(tmp_path, mode):
     """train_step with per-rank data on 2 gloo ranks: the data-dependent ActNorm initialisation is broadcast before the
     first optimizer step, a non-finite / too large loss on ONE rank makes EVERY rank drop the update (train.py:113-126),
-    parameters stay finite and bit-identical across the replicas (asserted inside the workers)."""
+    parameters stay finite and bit-identical across the replicas (asserted inside the workers).  `_late`: the same
+    with `late_check=True` (guards after the backward pass, gradients all-reduced only after the collective decision)."""
     out = str(tmp_path / f"s_{mode}.npz")
     _run(2, out, "_ddp_step_worker.py", mode)
     r = np.load(out)
