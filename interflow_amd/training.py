@@ -42,10 +42,13 @@ class GradientAllReducer:
             size += n
         if cur:
             self._close(cur)
-        self._bucket_of = {}
+        self._bucket_of, self._offset_of = {}, {}
         for bi, b in enumerate(self.buckets):
+            o = 0
             for p in b["params"]:
                 self._bucket_of[id(p)] = bi
+                self._offset_of[id(p)] = o          # (looked up by every gradient hook: no linear search per call)
+                o += p.numel()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.defer = False            # True: the hooks launch nothing; finish() reduces every bucket (train_step's late_check)
         self.zero_grad()
@@ -82,14 +85,8 @@ class GradientAllReducer:
         if b["pending"] == 0 and not b["launched"] and not self.defer:
             self._launch(b)
 
-    @staticmethod
-    def _offset(b, p):
-        o = 0
-        for q in b["params"]:
-            if q is p:
-                return o
-            o += q.numel()
-        raise KeyError
+    def _offset(self, b, p):
+        return self._offset_of[id(p)]
 
     def finish(self):
         """Call after backward(): reduce the buckets whose parameters did not all receive a gradient, wait, average."""
