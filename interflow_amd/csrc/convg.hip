@@ -103,6 +103,21 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
     for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(0, i);
 
+    // The weights come from global memory (L2) straight into registers, PD k-steps ahead of their use and across the chunk
+    // boundary: with one or two waves per SIMD nothing else hides the L2 latency, and at a distance of one k-step (four
+    // matrix instructions, 0.12 us) every k-step waited for its load -- 27 us for a launch whose arithmetic takes 5.
+    constexpr int ITERS = TAPS * KQW;
+    constexpr int PD = ITERS < 4 ? ITERS : 4;
+    auto wptr = [&](int cc, int it, int m) -> const f32x4* {
+        const int tap = it / KQW, kq = it % KQW;
+        return (const f32x4*)(wl + (int64_t)cc * (TAPS * KQ * 256) + m * wrec + (tap * KQ + kq) * 256);
+    };
+    f32x4 wnext[PD][MT];
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wnext[p][m] = *wptr(0, p, m);
+
     for (int cc = 0; cc < nchunks; ++cc) {
         __syncthreads();
 #pragma unroll
@@ -111,30 +126,36 @@ void convg_kernel(IflConvArgs a)
             *(f32x4*)&lds[(idx >> 3) * IFL_CS + (idx & 7) * 4] = stage[i];
         }
         __syncthreads();
-        if (cc + 1 < nchunks) {
+        const bool more = cc + 1 < nchunks;
+        if (more) {
 #pragma unroll
             for (int i = 0; i < LD_SLOTS; ++i) stage[i] = *(const f32x4*)chunk_src(cc + 1, i);
         }
-        const float* wc = wl + (int64_t)cc * (TAPS * KQ * 256);
-        constexpr int ITERS = TAPS * KQW;
-        f32x4 wq[2][MT], xb[2];
+        f32x4 wq[ITERS][MT], xb[2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wq[0][m] = *(const f32x4*)(wc + m * wrec);
+        for (int p = 0; p < PD; ++p)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) wq[p][m] = wnext[p][m];
         xb[0] = *(const f32x4*)((const char*)lds + a0);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
+            if (it + PD < ITERS) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wq[it + PD][m] = *wptr(cc, it + PD, m);
+            } else if (more) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wnext[it + PD - ITERS][m] = *wptr(cc + 1, it + PD - ITERS, m);
+            }
             if (it + 1 < ITERS) {
                 const int tap = (it + 1) / KQW, kq = (it + 1) % KQW;
                 const int tapoff = TAPS == 9 ? ((tap / 3) * t.PW + (tap % 3)) * (IFL_CS * 4) : 0;
                 xb[(it + 1) & 1] = *(const f32x4*)((const char*)lds + a0 + tapoff + kq * 32);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) wq[(it + 1) & 1][m] = *(const f32x4*)(wc + m * wrec + (tap * KQ + kq) * 256);
             }
             const int half = HALF ? 0 : ((it % KQW) >> 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[half][m] = mfma32(wq[it & 1][m][e], xb[it & 1][e], acc[half][m]);
+                for (int m = 0; m < MT; ++m) acc[half][m] = mfma32(wq[it][m][e], xb[it & 1][e], acc[half][m]);
         }
     }
 

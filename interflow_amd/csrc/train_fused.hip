@@ -35,80 +35,132 @@ int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, con
 
 namespace {
 
-constexpr int APX = 128;                      // pixels per block of the affine_px kernels
+constexpr int APX = 32;                       // pixels per wave (= per block, = per partial-sum slot) of the affine_px kernels
+
+// The per-pixel affine maps are small GEMMs ([pixels x C] by [C x C]) on v_mfma_f32_16x16x4_f32: A lane (row l & 15, k-slot
+// l >> 4), B lane (column l & 15, k-slot l >> 4), D lane (column l & 15, rows 4 (l >> 4) + r).  The k index a (step, slot)
+// pair stands for is free as long as A and B agree: for C = 48 slot g takes k = 16 S + 4 g + e (one float4 per lane and S),
+// for C = 12 k = 3 g + s.  One wave = 32 pixels (two column tiles).  (The first form, one thread per pixel with the matrix
+// in LDS, ran a group of four 40x40 samples on 25-50 workgroups: 19 us forward, 46 us backward per flow step.)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 template <int C>
-__global__ __launch_bounds__(256)
+struct AffK {                                 // the k indices of lane group g: NK of them, k(q) for q = 0 .. NK-1
+    static constexpr int NK = C / 4;
+    __device__ static int k(int q, int g) { return C == 48 ? 16 * (q >> 2) + 4 * g + (q & 3) : 3 * g + q; }
+};
+
+// v[q] = row[k(q, g)] (row: C contiguous floats; zero when !ok)
+template <int C>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int g, bool ok, float (&v)[C / 4]) {
+    if constexpr (C == 48) {
+#pragma unroll
+        for (int S = 0; S < 3; ++S) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (ok) t = *(const f32x4*)(row + 16 * S + 4 * g);
+            v[4 * S] = t[0]; v[4 * S + 1] = t[1]; v[4 * S + 2] = t[2]; v[4 * S + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) v[q] = ok ? row[3 * g + q] : 0.f;
+    }
+}
+
+// zo[p][i] = sum_j M[i][j] z[p][j] + c[i]
+template <int C>
+__global__ __launch_bounds__(64)
 void affine_px_fwd_kernel(const float* __restrict__ z, float* __restrict__ zo, const float* __restrict__ M,
                           const float* __restrict__ c, int64_t npx)
 {
-    __shared__ float sM[C * C + C];
-    for (int i = threadIdx.x; i < C * C + C; i += 256) sM[i] = i < C * C ? M[i] : c[i - C * C];
-    __syncthreads();
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npx) return;
-    float v[C];
+    constexpr int IT = (C + 15) / 16, NK = C / 4;
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * APX;
+    float am[IT][NK], bz[2][NK];
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-        const f32x4 t = *(const f32x4*)(z + p * C + q * 4);
-        v[q * 4] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
-    }
-    for (int q = 0; q < C / 4; ++q) {
-        f32x4 o;
+    for (int it = 0; it < IT; ++it) load_row<C>(M + (int64_t)(it * 16 + n) * C, g, it * 16 + n < C, am[it]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = q * 4 + e;
-            float a = sM[C * C + i];
+    for (int t = 0; t < 2; ++t) load_row<C>(z + (p0 + t * 16 + n) * C, g, p0 + t * 16 + n < npx, bz[t]);
 #pragma unroll
-            for (int j = 0; j < C; ++j) a = __builtin_fmaf(sM[i * C + j], v[j], a);
-            o[e] = a;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool rows = it * 16 + 4 * g < C;               // (C = 12: rows 12..15 of the only tile do not exist)
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (rows) d = *(const f32x4*)(c + it * 16 + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NK; ++q) d = mfma16(am[it][q], bz[t][q], d);     // (every lane takes part: no divergence here)
+            if (rows && p0 + t * 16 + n < npx) *(f32x4*)(zo + (p0 + t * 16 + n) * C + it * 16 + 4 * g) = d;
         }
-        *(f32x4*)(zo + p * C + q * 4) = o;
-    }
 }
 
 // dz = M^T dzo;  part[block][i * C + j] = sum_p dzo[p][i] z[p][j],  part[block][C * C + i] = sum_p dzo[p][i]
 template <int C>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void affine_px_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dzo, const float* __restrict__ M,
                           float* __restrict__ dz, float* __restrict__ part, int64_t npx)
 {
-    constexpr int S = C + 1;                  // odd row stride: the per-pixel rows of consecutive threads start in distinct banks
-    __shared__ float sM[C * C];
-    __shared__ float sz[APX * S], sg[APX * S];
+    constexpr int IT = (C + 15) / 16, NK = C / 4;
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
     const int64_t p0 = (int64_t)blockIdx.x * APX;
-    for (int i = threadIdx.x; i < C * C; i += 256) sM[i] = M[i];
-    for (int i = threadIdx.x; i < APX * C; i += 256) {
-        const int p = i / C, k = i - p * C;
-        const bool in = p0 + p < npx;
-        sz[p * S + k] = in ? z[p0 * C + i] : 0.f;
-        sg[p * S + k] = in ? dzo[p0 * C + i] : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < APX && p0 + threadIdx.x < npx) {
-        const float* g = sg + threadIdx.x * S;
-        float* o = dz + (p0 + threadIdx.x) * C;
-        for (int q = 0; q < C / 4; ++q) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < C; ++i) {
-                const float gi = g[i];
+    // ---- dz[p][j] = sum_i M[i][j] dzo[p][i]: A = M^T (row j, k = i), B = dzo (column p, k = i)
+    {
+        float bg[2][NK];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(sM[i * C + q * 4 + e], gi, a[e]);
+        for (int t = 0; t < 2; ++t) load_row<C>(dzo + (p0 + t * 16 + n) * C, g, p0 + t * 16 + n < npx, bg[t]);
+#pragma unroll
+        for (int jt = 0; jt < IT; ++jt) {
+            float at[NK];
+#pragma unroll
+            for (int q = 0; q < NK; ++q) at[q] = jt * 16 + n < C ? M[(int64_t)AffK<C>::k(q, g) * C + jt * 16 + n] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NK; ++q) d = mfma16(at[q], bg[t][q], d);
+                if (jt * 16 + 4 * g < C && p0 + t * 16 + n < npx) *(f32x4*)(dz + (p0 + t * 16 + n) * C + jt * 16 + 4 * g) = d;
             }
-            *(f32x4*)(o + q * 4) = a;
         }
+    }
+    // ---- part[i][j] = sum_p dzo[p][i] z[p][j]: k = pixel p0 + 4 s + g; A lane: dzo[p][it*16 + n], B lane: z[p][jt*16 + n]
+    f32x4 acc[IT][IT];
+    float sa[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        sa[it] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < IT; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < APX / 4; ++s) {
+        const int64_t p = p0 + 4 * s + g;
+        const bool in = p < npx;
+        float a[IT], b[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool ok = in && it * 16 + n < C;
+            a[it] = ok ? dzo[p * C + it * 16 + n] : 0.f;
+            b[it] = ok ? z[p * C + it * 16 + n] : 0.f;
+            sa[it] += a[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < IT; ++jt) acc[it][jt] = mfma16(a[it], b[jt], acc[it][jt]);
     }
     float* out = part + (int64_t)blockIdx.x * (C * C + C);
-    for (int e = threadIdx.x; e < C * C + C; e += 256) {
-        float a = 0.f;
-        if (e < C * C) {
-            const int i = e / C, j = e - i * C;
-            for (int p = 0; p < APX; ++p) a = __builtin_fmaf(sg[p * S + i], sz[p * S + j], a);
-        } else {
-            const int i = e - C * C;
-            for (int p = 0; p < APX; ++p) a += sg[p * S + i];
-        }
-        out[e] = a;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+#pragma unroll
+        for (int jt = 0; jt < IT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + 4 * g + r, j = jt * 16 + n;
+                if (i < C && j < C) out[i * C + j] = acc[it][jt][r];
+            }
+        float t = sa[it];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (g == 0 && it * 16 + n < C) out[C * C + it * 16 + n] = t;
     }
 }
 
@@ -317,13 +369,13 @@ void wino4_dw_kernel(const float* __restrict__ dU, int64_t rows_total, const ifl
 
 template <int C>
 int launch_affine_fwd(const float* z, float* zo, const float* M, const float* c, int64_t npx, hipStream_t st) {
-    hipLaunchKernelGGL(affine_px_fwd_kernel<C>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, z, zo, M, c, npx);
+    hipLaunchKernelGGL(affine_px_fwd_kernel<C>, dim3((unsigned)((npx + APX - 1) / APX)), dim3(64), 0, st, z, zo, M, c, npx);
     IFL_LAUNCH_CHECK();
     return 0;
 }
 template <int C>
 int launch_affine_bwd(const float* z, const float* dzo, const float* M, float* dz, float* part, int64_t npx, hipStream_t st) {
-    hipLaunchKernelGGL(affine_px_bwd_kernel<C>, dim3((unsigned)((npx + APX - 1) / APX)), dim3(256), 0, st, z, dzo, M, dz, part, npx);
+    hipLaunchKernelGGL(affine_px_bwd_kernel<C>, dim3((unsigned)((npx + APX - 1) / APX)), dim3(64), 0, st, z, dzo, M, dz, part, npx);
     IFL_LAUNCH_CHECK();
     return 0;
 }

@@ -87,8 +87,13 @@ void an_relu_bwd_kernel(const float* __restrict__ x, int xs, const float* __rest
 
 __device__ __forceinline__ float sigmoid2(float p) { return 1.0f / (1.0f + expf(-(p + 2.0f))); }
 
-constexpr int CPX = 256;                      // pixels per block of the coupling kernels: thread = pixel, loop over channel pairs
+constexpr int CPX = 32;                       // pixels per block of the coupling kernels
 
+// Thread = (pixel row r, channel c): the R = 256 / C rows of a block walk its CPX pixels, lanes run along the channels
+// (consecutive addresses in z; (shift, scale) pairs of 8 bytes in h), and a thread's channel -- hence its exp(3 logs3) -- is
+// fixed.  (One thread per pixel with a loop over the channels, the first form of these kernels, ran a group of four 40x40
+// samples on 28 workgroups: 20-30 us each, four of them on every flow step's critical path.)
+//
 // z, zout [B][h][w][C] contiguous; hr ringed [B][h+2][w+2][hs] with rows (2 i, 2 i + 1) = (shift, scale) of channel c0 + i;
 // ldpart[b][blk] = this block's signed sum of log scale (blocks never straddle samples: grid (ceil(h w / CPX), B))
 __global__ __launch_bounds__(256)
@@ -98,23 +103,27 @@ void coupling_fwd_kernel(const float* __restrict__ z, float* __restrict__ zout, 
 {
     __shared__ float red[4];
     const int b = blockIdx.y, hw = h * w;
-    const int p = blockIdx.x * CPX + threadIdx.x;
+    const int R = 256 / C;
+    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    const bool coupled = r < R && c >= c0 && c < c0 + n;
+    const int i = c - c0;
+    float e0 = 0.f, e1 = 0.f;
+    if (coupled) { e0 = expf(logs3[2 * i] * 3.0f); e1 = expf(logs3[2 * i + 1] * 3.0f); }
     float ld = 0.f;
-    if (p < hw) {
-        const int y = p / w, x = p - y * w;
-        const float* zp = z + ((int64_t)b * hw + p) * C;
-        float* zo = zout + ((int64_t)b * hw + p) * C;
-        const float* hp = hr + (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs;
-        for (int c = 0; c < C; ++c) {
-            float v = zp[c];
-            if (c >= c0 && c < c0 + n) {
-                const int i = c - c0;
-                const float sh = hp[2 * i] * expf(logs3[2 * i] * 3.0f);
-                const float sc = sigmoid2(hp[2 * i + 1] * expf(logs3[2 * i + 1] * 3.0f)) + eps;
+    if (r < R) {
+        const int pend = min((int)(blockIdx.x + 1) * CPX, hw);
+        for (int p = blockIdx.x * CPX + r; p < pend; p += R) {
+            const int64_t o = ((int64_t)b * hw + p) * C + c;
+            float v = z[o];
+            if (coupled) {
+                const int y = p / w, x = p - y * w;
+                const float2 hh = *(const float2*)(hr + (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs + 2 * i);
+                const float sh = hh.x * e0;
+                const float sc = sigmoid2(hh.y * e1) + eps;
                 if (branch == 0) { v = v + sh; v = v * sc; ld += logf(sc); }
                 else { v = v / sc; v = v - sh; ld -= logf(sc); }
             }
-            zo[c] = v;
+            zout[o] = v;
         }
     }
 #pragma unroll
@@ -133,55 +142,55 @@ void coupling_bwd_kernel(const float* __restrict__ z, const float* __restrict__ 
                          int n, float* __restrict__ dz, float* __restrict__ dh, float* __restrict__ lpart,
                          float* __restrict__ bpart, int h, int w, int C)
 {
-    extern __shared__ float sm[];             // [4 waves][2n] sums for d logs3, then [4 waves][2n] for d bias
+    __shared__ float sm[256 * 4];             // [row r][channel c][l0, l1, b0, b1]
     const int b = blockIdx.y, hw = h * w;
-    const int p = blockIdx.x * CPX + threadIdx.x;
+    const int R = 256 / C;
+    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    const bool coupled = r < R && c >= c0 && c < c0 + n;
+    const int i = c - c0;
     const float gl = dld ? dld[b] : 0.f;
-    const bool live = p < hw;
-    const int pc = live ? p : hw - 1;
-    const int y = pc / w, x = pc - y * w;
-    const float* zp = z + ((int64_t)b * hw + pc) * C;
-    const float* gp = dzo + ((int64_t)b * hw + pc) * C;
-    float* dzp = dz + ((int64_t)b * hw + pc) * C;
-    const int64_t ro = (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (live)
-        for (int c = 0; c < c0; ++c) dzp[c] = gp[c];
-    for (int i = 0; i < n; ++i) {
-        const int c = c0 + i;
-        const float e0 = expf(logs3[2 * i] * 3.0f), e1 = expf(logs3[2 * i + 1] * 3.0f);
-        const float hs0 = hr[ro + 2 * i] * e0, hs1 = hr[ro + 2 * i + 1] * e1;
-        const float sg = sigmoid2(hs1), sc = sg + eps;
-        const float g = gp[c], v = zp[c];
-        float dsh, dsc, dzi;
-        if (branch == 0) { dzi = g * sc; dsh = dzi; dsc = g * (v + hs0) + gl / sc; }
-        else { dzi = g / sc; dsh = -g; dsc = -g * v / (sc * sc) - gl / sc; }
-        const float dp = dsc * sg * (1.0f - sg);
-        float l0 = 0.f, l1 = 0.f, b0 = 0.f, b1 = 0.f;
-        if (live) {
-            dzp[c] = dzi;
-            b0 = dsh * e0;
-            b1 = dp * e1;
-            dh[ro + 2 * i] = b0;
-            dh[ro + 2 * i + 1] = b1;
-            l0 = dsh * hs0 * 3.0f;
-            l1 = dp * hs1 * 3.0f;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64); }
-        if (lane == 0) { sm[wave * 2 * n + 2 * i] = l0; sm[wave * 2 * n + 2 * i + 1] = l1; }
-        if (bpart) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64); }
-            if (lane == 0) { sm[(4 + wave) * 2 * n + 2 * i] = b0; sm[(4 + wave) * 2 * n + 2 * i + 1] = b1; }
+    float e0 = 0.f, e1 = 0.f;
+    if (coupled) { e0 = expf(logs3[2 * i] * 3.0f); e1 = expf(logs3[2 * i + 1] * 3.0f); }
+    float l0 = 0.f, l1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (r < R) {
+        const int pend = min((int)(blockIdx.x + 1) * CPX, hw);
+        for (int p = blockIdx.x * CPX + r; p < pend; p += R) {
+            const int64_t o = ((int64_t)b * hw + p) * C + c;
+            const float g = dzo[o];
+            float dzi = g;
+            if (coupled) {
+                const int y = p / w, x = p - y * w;
+                const int64_t ro = (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * hs + 2 * i;
+                const float2 hh = *(const float2*)(hr + ro);
+                const float v = z[o];
+                const float hs0 = hh.x * e0, hs1 = hh.y * e1;
+                const float sg = sigmoid2(hs1), sc = sg + eps;
+                float dsh, dsc;
+                if (branch == 0) { dzi = g * sc; dsh = dzi; dsc = g * (v + hs0) + gl / sc; }
+                else { dzi = g / sc; dsh = -g; dsc = -g * v / (sc * sc) - gl / sc; }
+                const float dp = dsc * sg * (1.0f - sg);
+                const float2 d = {dsh * e0, dp * e1};
+                *(float2*)(dh + ro) = d;
+                b0 += d.x;
+                b1 += d.y;
+                l0 += dsh * hs0 * 3.0f;
+                l1 += dp * hs1 * 3.0f;
+            }
+            dz[o] = dzi;
         }
     }
-    if (live)
-        for (int c = c0 + n; c < C; ++c) dzp[c] = gp[c];
+    if (r < R) {
+        float* q = sm + (r * C + c) * 4;
+        q[0] = l0; q[1] = l1; q[2] = b0; q[3] = b1;
+    }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * n; k += 256) {
-        lpart[((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k] = (sm[k] + sm[2 * n + k]) + (sm[4 * n + k] + sm[6 * n + k]);
-        if (bpart) bpart[((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k] = (sm[8 * n + k] + sm[10 * n + k]) + (sm[12 * n + k] + sm[14 * n + k]);
+    if (threadIdx.x < 2 * n) {                // one thread per row of h: channel i = k / 2, (shift | scale) = k & 1
+        const int k = threadIdx.x, cc = c0 + (k >> 1), e = k & 1;
+        float tl = 0.f, tb = 0.f;
+        for (int rr = 0; rr < R; ++rr) { tl += sm[(rr * C + cc) * 4 + e]; tb += sm[(rr * C + cc) * 4 + 2 + e]; }
+        const int64_t slot = ((int64_t)b * gridDim.x + blockIdx.x) * 2 * n + k;
+        lpart[slot] = tl;
+        if (bpart) bpart[slot] = tb;
     }
 }
 
@@ -233,7 +242,8 @@ extern "C" int ifl_coupling_fwd(const float* z, float* zout, const float* h_ring
                                 int c0, int n, float* ldpart, int B, int h, int w, int C, void* stream)
 {
     IFL_CHECK_ARG(z && zout && h_ring && logs3 && ldpart, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1 && C <= 256, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(hstride % 2 == 0, IFL_EINVAL, "odd row stride %d", hstride);
     IFL_CHECK_ARG(c0 >= 0 && n >= 1 && c0 + n <= C && 2 * n <= hstride, IFL_EINVAL, "channel range [%d, %d) of %d, %d rows", c0, c0 + n, C, hstride);
     IFL_CHECK_ARG(branch == 0 || branch == 1, IFL_EINVAL, "branch %d", branch);
     hipLaunchKernelGGL(coupling_fwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 0, (hipStream_t)stream, z, zout, h_ring, hstride,
@@ -247,10 +257,11 @@ int ifl_k_coupling_bwd(const float* z, const float* dzout, const float* dld, con
                        int h, int w, int C, hipStream_t stream)
 {
     IFL_CHECK_ARG(z && dzout && h_ring && logs3 && dz && dh_ring && dlogs_part, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && C >= 1 && C <= 256, IFL_EINVAL, "bad shape");
+    IFL_CHECK_ARG(hstride % 2 == 0, IFL_EINVAL, "odd row stride %d", hstride);
     IFL_CHECK_ARG(c0 >= 0 && n >= 1 && c0 + n <= C && 2 * n <= hstride && n <= 64, IFL_EINVAL, "channel range [%d, %d) of %d, %d rows", c0, c0 + n, C, hstride);
     IFL_CHECK_ARG(branch == 0 || branch == 1, IFL_EINVAL, "branch %d", branch);
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 16 * n * sizeof(float), stream, z, dzout, dld,
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ifl_coupling_blocks(h, w), B), dim3(256), 0, stream, z, dzout, dld,
                        h_ring, hstride, logs3, eps, branch, c0, n, dz, dh_ring, dlogs_part, dbias_part, h, w, C);
     IFL_LAUNCH_CHECK();
     return 0;

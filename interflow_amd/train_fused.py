@@ -441,10 +441,19 @@ class _Lease:
         self.release()
 
 
+MARK = None            # tools/phase_events.py: a callable(name) invoked at the phase boundaries of the level drivers
+
+
+def _mark(name):
+    if MARK is not None:
+        MARK(name)
+
+
 class _LevelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, ft_ring, z, M_all, c_all, *params):
         L = _lib()
+        _mark("before level")
         plan.busy = True
         ctx.lease = _Lease(plan)
         ctx.ft_ring = ft_ring                           # the backward reads it (weight gradients of the first convolutions)
@@ -454,11 +463,14 @@ class _LevelFn(torch.autograd.Function):
             plan.c.copy_(c_all)
             plan.level.ft = ft_ring.data_ptr() if ft_ring is not None else None
             plan.run_table(plan.pack_tab)
+            _mark("pack")
             if plan.bulk:
                 hip.check(L.ifl_train_bulk_conv1(hip._ptr(ft_ring), hip._ptr(plan.vg), hip._ptr(plan.wx), 2 * WX_FLOATS, plan.nc,
                                                  hip._ptr(plan.raw), plan.raw[0].numel(), plan.B, plan.h, plan.w, hip._stream()),
                           "ifl_train_bulk_conv1")
+            _mark("bulk conv1")
             hip.check(L.ifl_train_level_fwd(ctypes.byref(plan.level), hip._stream()), "ifl_train_level_fwd")
+            _mark("level fwd")
             ld = plan.ldpart.sum(dim=(0, 1, 3))
         return plan.z_last.clone(), ld
 
@@ -474,9 +486,11 @@ class _LevelFn(torch.autograd.Function):
         C = plan.C
         with torch.cuda.device(plan.device):
             plan.level.ft = ctx.ft_ring.data_ptr() if ctx.ft_ring is not None else None
+            _mark("before level bwd")
             plan.dW.zero_()
             hip.check(L.ifl_train_level_bwd(ctypes.byref(plan.level), hip._ptr(gz), hip._ptr(gld), hip._ptr(plan.dz_in), hip._stream()),
                       "ifl_train_level_bwd")
+            _mark("level bwd")
             dMc = plan.dM_part.sum(dim=1)                                  # [steps, C*C + C]
             dz = plan.dz_in.clone()
             direct = _direct_grad and all(p.grad is not None and p.grad.dtype == torch.float32 for p in plan.params)
