@@ -21,6 +21,7 @@ ActNorm2d (FlowActNorms.py:45-97), InvertibleConv1x1 (Permutations.py:76-123).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
@@ -43,12 +44,13 @@ _direct_grad = False
 # the multi-tensor add) on a second stream, so that it runs beside the next level's sequential chain of small kernels;
 # leaving the `accumulate_into_grad()` block joins that stream.
 SIDE_STREAM = os.environ.get("IFL_TRAIN_SIDE_STREAM", "1") != "0"
+WINO_FORK = os.environ.get("IFL_TRAIN_WINO_FORK", "1") != "0"
 _side = {}
 _pending = set()
 
 
-def _side_stream(device):
-    key = torch.device(device).index
+def _side_stream(device, which=0):
+    key = (torch.device(device).index, which)
     if key not in _side:
         _side[key] = torch.cuda.Stream(device=device)
     return _side[key]
@@ -512,16 +514,27 @@ class _LevelFn(torch.autograd.Function):
         """Weight gradients of the level's coupling networks from what the chain saved, brought into the parameters' layout;
         `direct`: added into the parameters' .grad here (one multi-tensor add), else returned."""
         L = _lib()
+        fork = None
+        if plan.wino_wgrad and direct and SIDE_STREAM and WINO_FORK:
+            # the Winograd-domain part (two transforms, 36 GEMMs) on a stream of its own beside the batched weight gradients:
+            # both are one-round launches at a fraction of the matrix peak, and the last level's weight phase is the step's tail
+            cur = torch.cuda.current_stream()
+            fork = _side_stream(plan.device, 1)
+            fork.wait_stream(cur)
         if plan.batched:
             plan.batched_wgrads(ft_ring)
         plan.run_table(plan.grad_tab)
         if plan.wino_wgrad:
             rows = plan.dM.shape[1]
-            hip.check(L.ifl_wino4_kmajor(0, hip._ptr(ft_ring), N_RRDB_CH, 1, 0, hip._ptr(plan.Vt), N_RRDB_CH, 0,
-                                         plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
-            hip.check(L.ifl_wino4_kmajor(1, hip._ptr(plan.dp1), 64, plan.dp1.shape[0], plan.dp1[0].numel(), hip._ptr(plan.dM), rows, 0,
-                                         plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
-            torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
+            ctx_ = torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext()
+            with ctx_:
+                hip.check(L.ifl_wino4_kmajor(0, hip._ptr(ft_ring), N_RRDB_CH, 1, 0, hip._ptr(plan.Vt), N_RRDB_CH, 0,
+                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+                hip.check(L.ifl_wino4_kmajor(1, hip._ptr(plan.dp1), 64, plan.dp1.shape[0], plan.dp1[0].numel(), hip._ptr(plan.dM), rows, 0,
+                                             plan.B, plan.h, plan.w, hip._stream()), "ifl_wino4_kmajor")
+                torch.bmm(plan.dM, plan.Vt.transpose(1, 2), out=plan.dU)
+            if fork is not None:
+                torch.cuda.current_stream().wait_stream(fork)         # (the map back to taps writes where the re-layout table wrote)
             hip.check(L.ifl_wino4_dw(hip._ptr(plan.dU), rows, hip._ptr(plan.wdst), plan.dp1.shape[0], hip._stream()), "ifl_wino4_dw")
         torch.sum(plan.an_part, dim=3, out=plan.an_sum)               # [cond steps, network, actnorm, 128]
         for t, o in zip(plan.cpl_part, plan.cpl_sum):                  # per network slot: [cond steps, (logs3 | bias3), 2n]
@@ -532,23 +545,52 @@ class _LevelFn(torch.autograd.Function):
         return [g.clone() for g in plan.grad_views]
 
 
+class _StackGroups(torch.autograd.Function):
+    """k stacks of n same-shaped parameters each (inputs: group 0's n tensors, then group 1's, ...).  torch.stack's own
+    backward hands every parameter its slice through AccumulateGrad -- one small add launch per parameter, 90 per level;
+    inside `accumulate_into_grad()` the slices go into the existing .grad tensors with one multi-tensor add instead."""
+
+    @staticmethod
+    def forward(ctx, k, *params):
+        n = len(params) // k
+        ctx.k, ctx.n, ctx.params = k, n, params
+        return tuple(torch.stack(params[g * n:(g + 1) * n]) for g in range(k))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        k, n, params = ctx.k, ctx.n, ctx.params
+        need = [(p, grads[i // n][i % n]) for i, p in enumerate(params) if ctx.needs_input_grad[1 + i] and grads[i // n] is not None]
+        if _direct_grad and all(p.grad is not None and p.grad.dtype == g.dtype for p, g in need):
+            if need:
+                torch._foreach_add_([p.grad for p, _ in need], [g for _, g in need])
+            return (None,) * (1 + len(params))
+        out = [None] * len(params)
+        for i, p in enumerate(params):
+            if ctx.needs_input_grad[1 + i] and grads[i // n] is not None:
+                out[i] = grads[i // n][i % n]
+        return (None,) + tuple(out)
+
+
 def _affine_maps(steps, C, pixels):
     """Per step: M = W diag(exp(logs)), c = M bias (ActNorm2d then InvertibleConv1x1), batched over the level's steps; and the
     level's data-independent log-det  pixels * sum_steps (sum logs + log|det W|)  (FlowActNorms.py:69-85, Permutations.py:76-101)."""
     dev = steps[0].actnorm.bias.device
-    logs = torch.stack([s.actnorm.logs.reshape(-1) for s in steps])
-    bias = torch.stack([s.actnorm.bias.reshape(-1) for s in steps])
     ics = [s.invconv for s in steps]
     if all(ic.LU for ic in ics):
+        logs, bias, l_raw, log_s, u_raw = _StackGroups.apply(5, *[s.actnorm.logs for s in steps], *[s.actnorm.bias for s in steps],
+                                                             *[ic.l for ic in ics], *[ic.log_s for ic in ics], *[ic.u for ic in ics])
+        logs, bias = logs.reshape(len(steps), -1), bias.reshape(len(steps), -1)
         l_mask = torch.tril(torch.ones(C, C, device=dev), -1)
         eye = torch.eye(C, device=dev)
-        l = torch.stack([ic.l for ic in ics]) * l_mask + eye
-        log_s = torch.stack([ic.log_s for ic in ics])
+        l = l_raw * l_mask + eye
         sign_s = torch.stack([ic.sign_s for ic in ics])
-        u = torch.stack([ic.u for ic in ics]) * l_mask.t() + torch.diag_embed(sign_s * torch.exp(log_s))
+        u = u_raw * l_mask.t() + torch.diag_embed(sign_s * torch.exp(log_s))
         W = torch.matmul(torch.stack([ic.p for ic in ics]), torch.matmul(l, u))
         dl = log_s.sum()
     else:
+        logs = torch.stack([s.actnorm.logs.reshape(-1) for s in steps])
+        bias = torch.stack([s.actnorm.bias.reshape(-1) for s in steps])
         from .train_flow import invconv_weight
         ws, dls = zip(*(invconv_weight(ic, False) for ic in ics))
         W, dl = torch.stack(ws), torch.stack(dls).sum()
@@ -611,14 +653,17 @@ def run_encode(fu, src, feats, ld):
         if plan is None:
             return None
         plans.append((plan, params, steps, C, h, w, lv))
-    for plan, params, steps, C, h, w, lv in plans:
+    # every level's affine maps first: their backward nodes (the chain rule to the ActNorm / LU parameters, some forty small
+    # launches per level) then run after the last level's backward -- beside the weight phase on the side stream -- and not
+    # between two levels on the critical path
+    maps = [_affine_maps(steps, C, h * w) for _, _, steps, C, h, w, _ in plans]
+    for (plan, params, steps, C, h, w, lv), (M, c, ld_const) in zip(plans, maps):
         z = squeeze_cl(z).contiguous()
         ft = feats.get(lv)
         ft_ring = None
         if any(plan.cond):
             assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h, w), (lv, None if ft is None else tuple(ft.shape))
             ft_ring = T.to_ring(ft.detach().float())
-        M, c, ld_const = _affine_maps(steps, C, h * w)
         z, ld_lv = _LevelFn.apply(plan, ft_ring, z, M, c, *params)
         ld = ld + ld_lv + ld_const
     return z.permute(0, 3, 1, 2).contiguous(), ld
