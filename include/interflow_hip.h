@@ -419,6 +419,17 @@ enum {
 int ifl_prof_enable(int mask);
 int ifl_prof_read(int kernel_id, double* total_ms, int64_t* count);
 
+/* ---- the optimizer update of the training step (train.py:53-56,130: torch.optim.Adam) as ONE launch over a device table ----
+ * Row = a chunk of at most IFL_ADAM_CHUNK elements of one parameter tensor with its gradient and moments (the caller splits
+ * tensors into chunks).  t = *step_in + 1; m += (g - m)(1 - beta1); v = beta2 v + (1 - beta2) g^2;
+ * p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps); *step_out = t.  *skip != 0 (device flag, may be NULL):
+ * nothing is written but *step_out = *step_in (the reference's loss guards train.py:113-126 decided on the device).
+ * step_in and step_out are two different device cells the caller alternates.  interflow_amd/training.py:TableAdam.      */
+enum { IFL_ADAM_CHUNK = 4096 };
+typedef struct ifl_adam_row { float* p; const float* g; float* m; float* v; int64_t n; } ifl_adam_row;
+int ifl_adam_table(const ifl_adam_row* table_dev, int n_rows, float lr, float beta1, float beta2, float eps,
+                   const float* step_in, float* step_out, const float* skip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

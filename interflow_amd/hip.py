@@ -128,6 +128,8 @@ def lib():
     L.ifl_resize_sep.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]
     L.ifl_resize_sep.restype = c_int
+    L.ifl_adam_table.argtypes = [c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.ifl_adam_table.restype = c_int
     L.ifl_prof_enable.argtypes = [c_int]
     L.ifl_prof_enable.restype = c_int
     L.ifl_prof_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(c_int64)]
@@ -140,6 +142,7 @@ def lib():
     return L
 
 
+ADAM_CHUNK = 4096             # IFL_ADAM_CHUNK of the header
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
@@ -147,7 +150,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo",
            "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep",
-           "ifl_pack_table", "ifl_affine_px_blocks", "ifl_train_level_fwd", "ifl_train_level_bwd", "ifl_train_vg_floats",
+           "ifl_adam_table", "ifl_pack_table", "ifl_affine_px_blocks", "ifl_train_level_fwd", "ifl_train_level_bwd", "ifl_train_vg_floats",
            "ifl_train_bulk_conv1", "ifl_wino4_tiles", "ifl_wino4_kmajor", "ifl_wino4_dw", "ifl_conv2d_wgrad_batched", "ifl_conv2d_batched")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)

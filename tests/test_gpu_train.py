@@ -534,3 +534,59 @@ def test_full_training_step_against_reference_golden(golden_dir):
     got_names = {n for n, p in named.items() if p.grad is not None}
     assert got_names == set(str(n) for n in g["grad_names"])
     print(f"1456 gradient checksums, worst relative sum-of-squares error {worst:.2e}")
+
+
+def test_table_adam_matches_torch_adam():
+    """training.TableAdam (ifl_adam_table, one launch) against torch.optim.Adam (train.py:53) over several steps, on tensors
+    of awkward sizes and misaligned gradient views; the device-side skip flag; state dict exchange with torch's Adam."""
+    from interflow_amd import training
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    shapes = [(64, 326, 3, 3), (1, 64, 1, 1), (7,), (4097,), (48, 48), (3, 5, 7)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev, generator=g)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    flat = torch.zeros(sum(p.numel() for p in pa) + 3, device=dev)
+    o = 3                                                        # gradients as views at an odd offset of one flat buffer
+    for p in pa:
+        p.grad = flat[o:o + p.numel()].view_as(p)
+        o += p.numel()
+    A = training.TableAdam(pa, lr=1e-3)
+    Bo = torch.optim.Adam(pb, lr=1e-3)
+    v0 = [p._version for p in pa]
+    for it in range(5):
+        for p, q in zip(pa, pb):
+            gr = torch.randn(p.shape, device=dev, generator=g) * (10.0 ** (it - 2))
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        A.step()
+        Bo.step()
+        for p, q in zip(pa, pb):
+            err = float((p - q).detach().abs().max())
+            assert err <= 2e-6 * max(1.0, float(q.detach().abs().max())), (it, tuple(p.shape), err)
+    assert all(p._version > v for p, v in zip(pa, v0)), "version counters must move (packed-weight caches key on them)"
+    assert float(A.state[pa[0]]["step"]) == 5.0
+    # skip flag: nothing moves, the step counter neither
+    before = [p.detach().clone() for p in pa]
+    m_before = A.state[pa[0]]["exp_avg"].clone()
+    A.found_inf = torch.ones((), device=dev)
+    A.step()
+    del A.found_inf
+    assert all(torch.equal(p, b) for p, b in zip(pa, before)) and torch.equal(A.state[pa[0]]["exp_avg"], m_before)
+    assert float(A.state[pa[0]]["step"]) == 5.0
+    # state dict: TableAdam -> torch Adam -> one more step on both gives the same parameters
+    import copy
+    sd = A.state_dict()
+    C = torch.optim.Adam(pb, lr=1e-3)
+    C.load_state_dict(copy.deepcopy(sd))                         # (load_state_dict keeps the tensors it is given: no aliasing between the two)
+    A2 = training.TableAdam(pa, lr=1e-3)
+    A2.load_state_dict(copy.deepcopy(sd))
+    for p, q in zip(pa, pb):
+        q.data.copy_(p.data)
+        gr = torch.randn(p.shape, device=dev, generator=g)
+        p.grad.copy_(gr)
+        q.grad = gr.clone()
+    A2.step()
+    C.step()
+    for p, q in zip(pa, pb):
+        assert float((p - q).detach().abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max()))
+    assert float(A2.state[pa[0]]["step"]) == 6.0
