@@ -374,7 +374,11 @@ class InterpFlow(nn.Module):
         of the classes.  No host tests on device data here (the reference's `any()` branch is a `where`)."""
         label = label.to(z.device)
         means, covs = self._shifted(z.device)
-        ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
+        if torch.is_grad_enabled() and (z.requires_grad or any(c.requires_grad for c in covs) or any(m.requires_grad for m in means)):
+            from . import train_flow
+            ll_all = train_flow.gaussian_logp_classes(torch.stack(means), torch.stack(covs), z)                  # (n, cls), all classes at once
+        else:
+            ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
         mask_label = self._class_table(z.device)[None, :] == label.reshape(-1, 1)
         ll = torch.zeros(z.shape[0], device=z.device)
         for i in range(len(self.classes)):

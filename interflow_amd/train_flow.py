@@ -256,6 +256,19 @@ class _InvLogdet(torch.autograd.Function):
         return g
 
 
+def gaussian_logp_classes(means, covs, x):
+    """Gaussian.logp (flow.py:138-161) of x [n, C, h, w] under K class priors at once: means [K, C], covs [K, C, C] ->
+    [n, K].  The same expressions as `gaussian_logp`, batched over the classes (one batched inverse / log-det and one
+    batched quadratic form instead of K of each: the loss sits between the forward and the backward chain, nothing overlaps it)."""
+    x_ = x.permute(0, 2, 3, 1)[None]                                              # [1, n, h, w, C]
+    x_c = x_ - means[:, None, None, None, :]                                        # [K, n, h, w, C]
+    k = x.shape[1]
+    cov_inv, logdet = _InvLogdet.apply(covs)                                        # [K, C, C], [K]
+    quad = (torch.matmul(x_c, cov_inv[:, None, None]) * x_c).sum(dim=4)             # [K, n, h, w]
+    lik = -0.5 * (logdet[:, None, None, None] + k * LOG2PI + quad)
+    return lik.sum(dim=(2, 3)).t()
+
+
 def gaussian_logp(mean, cov, x):
     """Gaussian.logp / likelihood, flow.py:138-161, differentiable (x is NCHW)."""
     if mean is None and cov is None:

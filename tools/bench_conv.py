@@ -18,7 +18,10 @@ def main():
     # (images, h, w, cin, cout, taps): one sample group (4 images) of the two flow levels, and the whole batch
     for (B, h, w, cin, cout, taps) in ((4, 40, 40, 64, 64, 9), (4, 40, 40, 32, 64, 9), (4, 40, 40, 64, 32, 9), (4, 40, 40, 64, 64, 1),
                                        (4, 80, 80, 64, 64, 9), (4, 80, 80, 32, 64, 9), (4, 80, 80, 64, 32, 9), (4, 80, 80, 64, 64, 1),
-                                       (8, 40, 40, 64, 64, 9), (8, 40, 40, 64, 64, 3 * 3)):
+                                       (8, 40, 40, 64, 64, 9),
+                                       # the conditioning encoder's dense blocks at batch 8
+                                       (8, 40, 40, 64, 32, 9), (8, 40, 40, 96, 32, 9), (8, 40, 40, 128, 32, 9), (8, 40, 40, 160, 32, 9), (8, 40, 40, 192, 64, 9),
+                                       (1, 40, 40, 64, 32, 9), (1, 40, 40, 192, 64, 9)):
         x = torch.randn(B, h + 2, w + 2, cin, device=dev)
         y = torch.zeros(B, h + 2, w + 2, cout, device=dev)
         wp = torch.randn(cout * cin * taps, device=dev)

@@ -10,13 +10,13 @@ import sys
 
 def main():
     src = sys.argv[1]
-    marker = sys.argv[2] if len(sys.argv) > 2 else "FusedOptimizer"
+    markers = [sys.argv[2]] if len(sys.argv) > 2 else ["adam_table_kernel", "FusedOptimizer"]
     rows = []
     for f in glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if marker in r[3]]
+    marks = [i for i, r in enumerate(rows) if any(m in r[3] for m in markers)]
     # groups of consecutive marker launches = one optimizer step; take the region between the last two groups
     groups = []
     for i in marks:
@@ -57,6 +57,18 @@ def main():
     print("gaps:", {k: (v[0], round(v[1] / 1e6, 2)) for k, v in hist.items()})
     for g, before, after in sorted(gaps, reverse=True)[:12]:
         print(f"  {g / 1e3:8.1f} us after {before[:45]:45s} before {after[:45]}")
+    # the step's kernels by total time (steady state: the data-dependent initialisation of the first step is not in it)
+    per_k = {}
+    for s, e, q, n in step:
+        k = n.split("(")[0][:90]
+        per_k.setdefault(k, [0, 0])
+        per_k[k][0] += e - s
+        per_k[k][1] += 1
+    tot = sum(v[0] for v in per_k.values())
+    print(f"kernels of the step: {len(step)} launches, {tot / 1e6:.2f} ms of kernel time")
+    print(f"  {'kernel':90s} {'calls':>6s} {'total us':>10s} {'avg us':>8s} {'%':>6s}")
+    for k, (t, c) in sorted(per_k.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f"  {k:90s} {c:6d} {t / 1e3:10.1f} {t / c / 1e3:8.1f} {100.0 * t / tot:6.1f}")
 
 
 if __name__ == "__main__":
