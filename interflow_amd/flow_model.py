@@ -171,8 +171,10 @@ class RRDBGlowNet(nn.Module):
     def _needs_autograd(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.RRDB.parameters())
 
-    def _rrdb_hip(self, lr):
-        """RRDBNet.forward(get_steps=True) + the stacking below, through ifl_rrdb_encode (inference only)."""
+    def _rrdb_hip(self, lr, outputs=None):
+        """RRDBNet.forward(get_steps=True) + the stacking below, through ifl_rrdb_encode (inference only).  outputs: the
+        feature maps the caller will read (None: all, as the reference); the others are None in the result and the layers
+        only they need (upconv2, HRconv, conv_last for 'fea_up4' / 'out') are not run."""
         import ctypes
         from . import pack
         lr = hip._dev_f32(lr, "rrdbPreprocessing input")
@@ -204,14 +206,17 @@ class RRDBGlowNet(nn.Module):
 
         def new(c, h, w):
             return torch.empty(B, c, h, w, dtype=torch.float32, device=lr.device)
-        up1, up2, up4 = new(Ct, H // 4, W // 4), new(Ct, H // 2, W // 2), new(Ct, H, W)
+        want = (lambda k: True) if outputs is None else (lambda k: k in outputs)
+        up1 = new(Ct, H // 4, W // 4)
+        up2 = new(Ct, H // 2, W // 2) if want('fea_up2') else None
+        up4 = new(Ct, H, W) if want('fea_up4') else None
         up0 = None
         if opt_get(self.opt, ['network_G', 'flow', 'fea_up0']) or False:
             if H // 8 == 0 or W // 8 == 0:                  # F.interpolate(scale_factor=1/2) of RRDBNet_arch.py:138 raises
                 raise RuntimeError(f"Input and output sizes should be greater than 0, but got input (H: {H // 4}, "
                                    f"W: {W // 4}) output (H: {H // 8}, W: {W // 8})")
             up0 = new(Ct, H // 8, W // 8)
-        out = new(3, H, W)
+        out = new(3, H, W) if want('out') else None
         blocks = torch.empty(len(block_idxs), B, 64, H // 4, W // 4, dtype=torch.float32, device=lr.device)
         idx = (ctypes.c_int * max(len(block_idxs), 1))(*block_idxs)
         with torch.cuda.device(lr.device):
@@ -226,11 +231,14 @@ class RRDBGlowNet(nn.Module):
             res["block_{}".format(k)] = blocks[i]
         return res
 
-    def rrdbPreprocessing(self, lr):
+    def rrdbPreprocessing(self, lr, outputs=None):
+        """RRDBGlowNet_arch.py:217-246.  outputs (an extension; default None = everything, as the reference): the names among
+        'fea_up1', 'fea_up2', 'fea_up4', 'out' the caller will read -- the K=16, L=2 flow only reads 'fea_up1' and 'fea_up2', and
+        the full-resolution tail (upconv2, HRconv, conv_last and a 262 MB 'fea_up4' at batch 8) is 6 % of the encoder pass."""
         concat_on = opt_get(self.opt, ['network_G', 'flow', 'stackRRDB', 'concat']) or False
         upn1 = opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False
         if not self._needs_autograd() and concat_on and not upn1:
-            return self._rrdb_hip(lr)
+            return self._rrdb_hip(lr, outputs)
         # autograd has to reach the encoder's parameters: the differentiable evaluation (every convolution on the HIP kernels)
         if not lr.is_cuda:
             raise hip.InterflowHipError(f"rrdbPreprocessing: tensor is on {lr.device}; there is no CPU path")

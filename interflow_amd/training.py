@@ -21,6 +21,11 @@ from typing import Iterable, List, Optional
 import torch
 
 
+# the conditioning maps the shipped K=16, L=2 flow reads (FlowUpsamplerNet.py:66-73: level 1 -> 'fea_up2', level 2 -> 'fea_up1');
+# the training step asks the frozen encoder for these only (its full-resolution tail feeds nothing the flow uses)
+FLOW_FEATURES = ("fea_up1", "fea_up2")
+
+
 class GradientAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], dist=None, bucket_bytes: int = 32 << 20):
         self.dist = dist
@@ -393,7 +398,7 @@ class EncoderPrefetcher:
             raise RuntimeError("EncoderPrefetcher needs a frozen encoder (arch.set_rrdb_training(False))")
         self.stream.wait_stream(torch.cuda.current_stream(gt.device))      # gt, and every earlier use of the encoder's buffers
         with torch.cuda.stream(self.stream), torch.no_grad():
-            feats = arch.rrdbPreprocessing(gt)
+            feats = arch.rrdbPreprocessing(gt, outputs=FLOW_FEATURES)
             done = torch.cuda.Event()
             done.record(self.stream)
         self.pending = (feats, done, gt)
@@ -432,7 +437,7 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
     if model.training:
         init_actnorm(model, gt, low_res, dist)
     if lr_enc is None:                                                                  # (given: EncoderPrefetcher's features of gt)
-        lr_enc = model.arch.rrdbPreprocessing(gt)                                       # train.py:72
+        lr_enc = model.arch.rrdbPreprocessing(gt, outputs=FLOW_FEATURES)                # train.py:72 (the maps the L=2 flow reads)
     if late_check:
         z, logdet = model(low_res, gt, lr_enc=lr_enc, add_gt_noise=add_gt_noise, calc_loss=False)    # :73
         nll, ib_loss = model.loss_terms(z, logdet, int(gt.size(2) * gt.size(3)), labels)             # :74

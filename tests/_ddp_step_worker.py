@@ -22,7 +22,7 @@ class Stub(torch.nn.Module):
         torch.manual_seed(0)
         self.conv = torch.nn.Conv2d(3, 4, 1)
         self.an = flow_modules.ActNorm2d(4)
-        self.arch = types.SimpleNamespace(rrdbPreprocessing=lambda gt: {"fea": gt})
+        self.arch = types.SimpleNamespace(rrdbPreprocessing=lambda gt, outputs=None: {"fea": gt})
 
     def forward(self, low_res, gt, label=None, lr_enc=None, add_gt_noise=True, calc_loss=True):
         h = self.conv(low_res).permute(0, 2, 3, 1)
