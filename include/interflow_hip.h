@@ -275,9 +275,13 @@ int ifl_coupling_bwd(const float* z, const float* dzout, const float* dld, const
  *   IFL_PACK_WINO4       input channels [real0, real0 + 320) of a 3x3 weight [64][cin_src][3][3] -> U = G g G^T in the 6x6
  *                        domain of Winograd F(4x4,3x3) (float64 arithmetic, rounded once), in the fragment order of the
  *                        bulk kernel (conv1x.hip): 64*320*36 floats
+ *   IFL_PACK_WINO4_T     the same input channels, for the data gradient wrt the conditioning features (the 'same'
+ *                        convolution of the output gradient with the 180-degree rotated taps): U' = G rot180(g) G^T written as
+ *                        dst[(p*320 + ci)*acnt + a0 + co], p = 0..35, co = 0..63 (a0 = the (step, network) pair's first column,
+ *                        acnt = the row length = 64 * pairs); nelem = 36*320*64
  * cin_src: the parameter's input-channel count (row length of src) when it differs from real0 + real1 (a weight of which
  * only some input channels are packed); 0 = real0 + real1.                                                           */
-enum { IFL_PACK_FWD = 0, IFL_PACK_TRANSPOSED = 1, IFL_PACK_VECTOR = 2, IFL_PACK_GRAD = 3, IFL_PACK_WINO4 = 4 };
+enum { IFL_PACK_FWD = 0, IFL_PACK_TRANSPOSED = 1, IFL_PACK_VECTOR = 2, IFL_PACK_GRAD = 3, IFL_PACK_WINO4 = 4, IFL_PACK_WINO4_T = 5 };
 typedef struct ifl_pack_desc {
     const float* src; float* dst; int64_t nelem;
     int32_t mode, cout_real, cout_pad, taps, real0, pad0, real1, pad1, a0, acnt, cin_src, pad_;
@@ -362,6 +366,11 @@ int64_t ifl_wino4_tiles(int B, int h, int w);
 int ifl_wino4_kmajor(int mode, const float* src, int C, int n_planes, int64_t plane_stride, float* out, int64_t rows_total,
                      int64_t row0, int B, int h, int w, void* stream);
 int ifl_wino4_dw(const float* dU, int64_t rows_total, const ifl_wino4_dst* table_dev, int n_pairs, void* stream);
+/* The gradient wrt the conditioning features (train.py:129 when the encoder is trained: RRDBGlowNet_arch.py:26-33) of all
+ * first convolutions of a level at once, in the Winograd domain: X = ifl_wino4_kmajor(mode 0) of the output-gradient planes
+ * [36][64*pairs][tiles], Y_p = U'_p X_p (36 plain GEMMs, U' from IFL_PACK_WINO4_T), and ifl_wino4_untile maps
+ * Y [36][C][tiles] back to pixels: out NCHW [B][C][h][w] = A^T Y A (every element written).                              */
+int ifl_wino4_untile(const float* Y, float* out_nchw, int C, int B, int h, int w, void* stream);
 int64_t ifl_train_vg_floats(int B, int h, int w);
 int ifl_train_bulk_conv1(const float* ft_ring, float* vg, const float* wx, int64_t wx_step, int nsteps, float* raw,
                          int64_t raw_step, int B, int h, int w, void* stream);

@@ -239,6 +239,22 @@ void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) u += G[pi][a] * (double)g[a * 3 + b] * G[pj][b];
             v = (float)u;
+        } else if (d.mode == IFL_PACK_WINO4_T) {
+            // U' = G rot180(g) G^T for the data gradient wrt the conditioning features: dst[(p*320 + ci)*acnt + a0 + co]
+            const int co = idx & 63;
+            const int ci = (int)((idx >> 6) % IFL_FT);
+            const int p = (int)((idx >> 6) / IFL_FT);
+            const int pi = p / 6, pj = p - pi * 6;
+            const float* g = d.src + ((int64_t)co * cin_real + d.real0 + ci) * 9;
+            const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double u = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) u += G[pi][a] * (double)g[(2 - a) * 3 + (2 - b)] * G[pj][b];
+            d.dst[((int64_t)p * IFL_FT + ci) * d.acnt + d.a0 + co] = (float)u;
+            continue;
         } else {                              // IFL_PACK_GRAD: dense [cout_pad][cin_pad][taps] -> the parameter's [cout][cin][taps]
             const int tap = idx % d.taps; int64_t r = idx / d.taps;
             const int ci = r % (d.real0 + d.real1), co = r / (d.real0 + d.real1);
@@ -367,6 +383,48 @@ void wino4_dw_kernel(const float* __restrict__ dU, int64_t rows_total, const ifl
         }
 }
 
+// Y [36][C][tiles] (Winograd domain, tile index contiguous) -> out = A^T Y A as an NCHW tensor [B][C][h][w]: the output
+// transform of F(4x4,3x3) for the data gradient wrt the conditioning features.  Thread = (tile, channel): the 64 lanes of a
+// wave read 256 contiguous bytes per position and write four-float row pieces of neighbouring tiles.
+__global__ __launch_bounds__(256)
+void wino4_untile_kernel(const float* __restrict__ Y, float* __restrict__ out, int C, IflXGeom g)
+{
+    const int64_t tile = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (tile >= g.ntiles || c >= C) return;
+    const int64_t T = g.ntiles;
+    const int tpi = g.TH * g.TW;
+    const int b = tile / tpi, r2 = tile - (int64_t)b * tpi;
+    const int tr = r2 / g.TW, tc = r2 - tr * g.TW;
+    float t[4][6];                                            // A^T m (rows), then (A^T m) A
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = Y[((int64_t)(i * 6 + j) * C + c) * T + tile];
+        t[0][j] = (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
+        t[1][j] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
+        t[2][j] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
+        t[3][j] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
+    }
+    float* base = out + ((int64_t)b * C + c) * g.H * g.W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = 4 * tr + r;
+        if (y >= g.H) break;
+        const float* m = t[r];
+        f32x4 o;
+        o[0] = (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
+        o[1] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
+        o[2] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
+        o[3] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
+        float* dst = base + (int64_t)y * g.W + 4 * tc;
+        if (4 * tc + 3 < g.W && (g.W & 3) == 0) *(f32x4*)dst = o;
+        else
+            for (int e = 0; e < 4; ++e) if (4 * tc + e < g.W) dst[e] = o[e];
+    }
+}
+
 template <int C>
 int launch_affine_fwd(const float* z, float* zo, const float* M, const float* c, int64_t npx, hipStream_t st) {
     hipLaunchKernelGGL(affine_px_fwd_kernel<C>, dim3((unsigned)((npx + APX - 1) / APX)), dim3(64), 0, st, z, zo, M, c, npx);
@@ -476,6 +534,17 @@ extern "C" int ifl_wino4_dw(const float* dU, int64_t rows_total, const ifl_wino4
     IFL_CHECK_ARG(dU && table_dev && n_pairs >= 1 && rows_total == (int64_t)n_pairs * 64, IFL_EINVAL, "wino4 dw: %d pairs", n_pairs);
     const int64_t n = rows_total * IFL_FT;
     hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dU, rows_total, table_dev);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ifl_wino4_untile(const float* Y, float* out_nchw, int C, int B, int h, int w, void* stream)
+{
+    IFL_CHECK_ARG(Y && out_nchw && C >= 1 && B >= 1 && h >= 1 && w >= 1, IFL_EINVAL, "wino4 untile: null pointer / shape");
+    const IflXGeom g = ifl_xgeom(B, h, w);
+    dim3 grid((unsigned)((g.ntiles + 63) / 64), (unsigned)((C + 3) / 4)), block(256);
+    IFL_CHECK_ARG(grid.y <= 65535, IFL_EINVAL, "wino4 untile: %d channels", C);
+    hipLaunchKernelGGL(wino4_untile_kernel, grid, block, 0, (hipStream_t)stream, Y, out_nchw, C, g);
     IFL_LAUNCH_CHECK();
     return 0;
 }

@@ -101,7 +101,7 @@ PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("nelem", "<i8"), ("mode"
                        ("cout_pad", "<i4"), ("taps", "<i4"), ("real0", "<i4"), ("pad0", "<i4"), ("real1", "<i4"),
                        ("pad1", "<i4"), ("a0", "<i4"), ("acnt", "<i4"), ("cin_src", "<i4"), ("pad_", "<i4")])
 assert PACK_DTYPE.itemsize == 72
-PACK_FWD, PACK_TRANSPOSED, PACK_VECTOR, PACK_GRAD, PACK_WINO4 = 0, 1, 2, 3, 4
+PACK_FWD, PACK_TRANSPOSED, PACK_VECTOR, PACK_GRAD, PACK_WINO4, PACK_WINO4_T = 0, 1, 2, 3, 4, 5
 WX_FLOATS = 36 * 64 * N_RRDB_CH          # one network's first-convolution weights in the 6x6 Winograd domain
 
 # The conditioning part of the first convolutions through the Winograd bulk kernel of the inference path (ifl_train_bulk_conv1)
@@ -133,6 +133,8 @@ def _lib():
     if not _bound:
         L.ifl_pack_table.argtypes = [c_void_p, ctypes.c_int, c_int64, c_void_p]
         L.ifl_pack_table.restype = ctypes.c_int
+        L.ifl_wino4_untile.argtypes = [c_void_p, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p]
+        L.ifl_wino4_untile.restype = ctypes.c_int
         L.ifl_affine_px_blocks.argtypes = [c_int64]
         L.ifl_affine_px_blocks.restype = c_int64
         L.ifl_train_level_fwd.argtypes = [POINTER(IflTrainLevel), c_void_p]
@@ -253,6 +255,7 @@ class LevelPlan:
         pack_rows, grad_rows, wdst_rows = [], [], []
         self.dW_first = []                                              # per network: dense gradient pointers of the first conditional step
         self.per_g = per_g
+        self.ut_rows, self.ut_tab = [], None                            # the data gradient wrt ft (ensure_ft_grad)
         self.param_slices = []                                          # per parameter of the function: how to find its gradient
         zi, ci = 0, 0
         wo = go = ro = 0
@@ -340,6 +343,9 @@ class LevelPlan:
                               dict(src=ptr(gv[1]), dst=ptr(rv[1]), nelem=rv[1].numel(), mode=PACK_GRAD, **common2),
                               dict(src=ptr(gv[2]), dst=ptr(rv[2]), nelem=rv[2].numel(), mode=PACK_GRAD, **common3)]
                 wdst_rows.append((ptr(rv[0]), (ch if z1 else 0) + N_RRDB_CH, ch if z1 else 0))
+                self.ut_rows.append(dict(src=ptr(w1), nelem=36 * N_RRDB_CH * 64, mode=PACK_WINO4_T, cout_real=64, cout_pad=64, taps=9,
+                                         real0=ch if z1 else 0, real1=N_RRDB_CH, cin_src=(ch if z1 else 0) + N_RRDB_CH,
+                                         a0=(ci * 2 + i) * 64, acnt=nc * 2 * 64))
                 self.param_slices += [("w", rv[0], w1.shape), ("an", (ci, i, 0, 0), an1b.shape), ("an", (ci, i, 0, 1), an1l.shape),
                                       ("w", rv[1], w2.shape), ("an", (ci, i, 1, 0), an2b.shape), ("an", (ci, i, 1, 1), an2l.shape),
                                       ("w", rv[2], w3.shape), ("cpl", (i, ci, 1), b3.shape), ("cpl", (i, ci, 0), l3.shape)]
@@ -360,16 +366,8 @@ class LevelPlan:
         self.z_first, self.z_last = self.z[0], self.z[zi]
         self.param_ptrs = tuple(p.data_ptr() for p in self.params)
 
-        def table(rows):
-            if not rows:
-                return None, 0, 0
-            arr = np.zeros(len(rows), dtype=PACK_DTYPE)
-            for k, r in enumerate(rows):
-                for key, v in r.items():
-                    arr[k][key] = v
-            return torch.from_numpy(arr.view(np.uint8)).to(device), len(rows), int(arr["nelem"].max())
-        self.pack_tab = table(pack_rows)
-        self.grad_tab = table(grad_rows)
+        self.pack_tab = self._table(pack_rows)
+        self.grad_tab = self._table(grad_rows)
 
         lv = IflTrainLevel()
         lv.B, lv.h, lv.w, lv.C, lv.ch, lv.nsteps, lv.branch, lv.ft_ch = B, h, w, C, ch, ns, 1, N_RRDB_CH
@@ -396,6 +394,47 @@ class LevelPlan:
             self.wdst = torch.from_numpy(arr.view(np.uint8)).to(device)
         self.level = lv
         self.nc = nc
+
+    def _table(self, rows):
+        if not rows:
+            return None, 0, 0
+        arr = np.zeros(len(rows), dtype=PACK_DTYPE)
+        for k, r in enumerate(rows):
+            for key, v in r.items():
+                arr[k][key] = v
+        return torch.from_numpy(arr.view(np.uint8)).to(self.device), len(rows), int(arr["nelem"].max())
+
+    @property
+    def can_ft_grad(self):
+        return self.bulk and hasattr(self, "dp1") and self.nc > 0
+
+    def ensure_ft_grad(self):
+        """Buffers of the gradient wrt the conditioning features (allocated when an encoder is trained): U' [36][320][64 pairs],
+        the transformed output gradients [36][64 pairs][tiles] and the product [36][320][tiles]."""
+        if self.ut_tab is None:
+            K = int(_lib().ifl_wino4_tiles(self.B, self.h, self.w))
+            rows = self.nc * 2 * 64
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self.Ut = torch.zeros(36, N_RRDB_CH, rows, **f32)
+            self.Xd = torch.zeros(36, rows, K, **f32)
+            self.Yd = torch.zeros(36, N_RRDB_CH, K, **f32)
+            self.ut_tab = self._table([dict(r, dst=self.Ut.data_ptr()) for r in self.ut_rows])
+
+    def ft_grad(self):
+        """d loss / d ft [B, 320, h, w] from the saved gradients wrt the first convolutions' outputs (call after the level's
+        backward): sum over all (step, network) pairs of the 'same' convolution with the rotated taps, as 36 GEMMs in the
+        Winograd F(4x4,3x3) domain (a quarter of the direct form's multiplications, one launch instead of 32 convolutions
+        and 31 adds of 262 MB tensors)."""
+        L = _lib()
+        self.ensure_ft_grad()
+        self.run_table(self.ut_tab)
+        rows = self.Xd.shape[1]
+        hip.check(L.ifl_wino4_kmajor(0, hip._ptr(self.dp1), 64, self.dp1.shape[0], self.dp1[0].numel(), hip._ptr(self.Xd), rows, 0,
+                                     self.B, self.h, self.w, hip._stream()), "ifl_wino4_kmajor")
+        torch.bmm(self.Ut, self.Xd, out=self.Yd)
+        dft = torch.empty(self.B, N_RRDB_CH, self.h, self.w, dtype=torch.float32, device=self.device)
+        hip.check(L.ifl_wino4_untile(hip._ptr(self.Yd), hip._ptr(dft), N_RRDB_CH, self.B, self.h, self.w, hip._stream()), "ifl_wino4_untile")
+        return dft
 
     def batched_wgrads(self, ft_ring):
         """The coupling networks' weight gradients of all conditional steps, one launch per (kind, network)."""
@@ -453,7 +492,9 @@ def _mark(name):
 
 class _LevelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, ft_ring, z, M_all, c_all, *params):
+    def forward(ctx, plan, ft_ring, ft_src, z, M_all, c_all, *params):
+        # ft_ring: the conditioning features as the kernels read them (ringed channels-last, no gradient); ft_src: the NCHW
+        # tensor they were made from when it needs a gradient (a trained encoder), else None
         L = _lib()
         _mark("before level")
         plan.busy = True
@@ -506,8 +547,9 @@ class _LevelFn(torch.autograd.Function):
                 _pending.add(side)
             else:
                 grads = _LevelFn._weight_phase(plan, ctx.ft_ring, direct)
+            dft = plan.ft_grad() if ctx.needs_input_grad[2] else None
         ctx.lease.release()
-        return (None, None, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
+        return (None, None, dft, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
 
     @staticmethod
     def _weight_phase(plan, ft_ring, direct):
@@ -604,9 +646,8 @@ def usable(fu, feats) -> bool:
     kinds = [k for k, _ in fu._kinds]
     if any(k not in ("squeeze", "step0", "stepc") for k in kinds):
         return False
-    for ft in feats.values():
-        if ft.requires_grad:
-            return False                      # gradients towards the conditioning encoder: the layer-by-layer path has them
+    if any(ft.requires_grad for ft in feats.values()) and not (USE_BULK and (WINO_WGRAD or BATCHED_WGRAD)):
+        return False                          # gradients towards the conditioning encoder come from the saved first-convolution gradients
     from .training import _uninitialised_actnorms
     if _uninitialised_actnorms(fu.layers):
         return False                          # data-dependent ActNorm initialisation is still due
@@ -664,6 +705,9 @@ def run_encode(fu, src, feats, ld):
         if any(plan.cond):
             assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h, w), (lv, None if ft is None else tuple(ft.shape))
             ft_ring = T.to_ring(ft.detach().float())
-        z, ld_lv = _LevelFn.apply(plan, ft_ring, z, M, c, *params)
+        ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
+        if ft_src is not None and not plan.can_ft_grad:
+            return None
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, z, M, c, *params)
         ld = ld + ld_lv + ld_const
     return z.permute(0, 3, 1, 2).contiguous(), ld

@@ -180,6 +180,32 @@ def test_fused_level_training_vs_oracle():
     assert rel(z2, z) < 1e-5 and rel(ld2, ld) < 1e-5 and rel(loss2, loss) < 1e-5
     for k, g in fused.items():
         assert rel(named[k].grad, g) < 2e-4, k
+    # gradients wrt the conditioning features (a trained encoder, RRDBGlowNet_arch.py:26-33): the level drivers' Winograd-domain
+    # data gradient (IFL_PACK_WINO4_T, ifl_wino4_kmajor, 36 GEMMs, ifl_wino4_untile) against the layer-by-layer path's
+    # per-convolution data gradients; the parameter gradients must not change
+    fg = {k: v.clone().requires_grad_(True) for k, v in fd.items()}
+
+    def step_ft():
+        model.zero_grad(set_to_none=True)
+        for v in fg.values():
+            v.grad = None
+        z_, nll_, _, ib_ = model(x.to(dev()), None, labels.to(dev()), lr_enc=fg, add_gt_noise=False)
+        (nll_.mean() - ib_.mean()).backward()
+        return {k: v.grad.clone() for k, v in fg.items() if v.grad is not None}
+    ga = step_ft()
+    assert all(p.ut_tab is not None and not p.busy for v in fu._train_plans.values() for p in v), "the level drivers did not produce d ft"
+    for k, g in fused.items():
+        assert rel(named[k].grad, g) < 1e-5, k
+    train_flow.FUSED_LEVELS = False
+    try:
+        gb = step_ft()
+    finally:
+        train_flow.FUSED_LEVELS = True
+    assert sorted(ga) == sorted(gb) == ["fea_up1", "fea_up2"], (sorted(ga), sorted(gb))
+    for k in ga:
+        e = rel(ga[k], gb[k])
+        print(f"d loss / d {k}: fused vs layer-by-layer {e:.2e}")
+        assert e < 2e-4, (k, e)
     # the level drivers with every first convolution in the direct form (no Winograd bulk launch), with the Winograd forward
     # but the direct weight-gradient kernel, with one weight-gradient launch per step instead of the batched ones, and with
     # one chain per level instead of two concurrent sample groups, and with fFeatures' network inside the chain
