@@ -398,6 +398,20 @@ int     ifl_rrdb_encode(const float* params, int nb, const int* block_idxs, int 
                         float* fea_up1, float* fea_up2, float* fea_up4, float* fea_up0, float* out, float* blocks_out,
                         int B, int H, int W, void* stream);
 
+/* The encoder with gradients (train.py:72,129 with network_G.train_RRDB; RRDBGlowNet_arch.py:26-33 makes its parameters
+ * trainable): ifl_rrdb_train_fwd is ifl_rrdb_encode for 'fea_up1' / 'fea_up2' (fea_up2 may be NULL) that keeps every dense
+ * block's buffer in `ws` (ifl_rrdb_train_ws_bytes bytes, ifl_rrdb_train_ws_init once: ~100 MB per 160x160 image at nb = 23);
+ * ifl_rrdb_train_bwd takes the gradients wrt those two outputs (NCHW, either may be NULL) and writes the gradient of every
+ * convolution it ran into d_params: [cout_pad][cin_pad][3][3] at w_off and the bias gradient at b_off of
+ * ifl_rrdb_conv_desc (zero d_params first).  params: as ifl_rrdb_encode; params_t: at the same offsets, each weight
+ * transposed and flipped for the data gradient (IFL_PACK_TRANSPOSED with a0 = 0, acnt = cin_pad).  One backward per forward. */
+int64_t ifl_rrdb_train_ws_bytes(int B, int H, int W, int nb);
+int     ifl_rrdb_train_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, int nb, void* stream);
+int     ifl_rrdb_train_fwd(const float* params, int nb, const int* block_idxs, int n_blocks, void* ws, const float* x,
+                           float* fea_up1, float* fea_up2, int B, int H, int W, void* stream);
+int     ifl_rrdb_train_bwd(const float* params_t, int nb, const int* block_idxs, int n_blocks, void* ws, const float* d_up1,
+                           const float* d_up2, float* d_params, int B, int H, int W, void* stream);
+
 /* Separable gather-resize: the antialiased cubic down-scaling of the LR-consistency loss, train.py:102-103 =
  * utils/resize_right.py:32-123 resize(x, 1/4, cubic, antialiasing=True).  x [N][Hin][Win] -> out [N][Hout][Wout], dimension -2
  * first, then -1, as the reference; per output index a field of view of T taps: idx*[out][T] (int32 input indices, clamped for

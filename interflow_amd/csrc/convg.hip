@@ -212,6 +212,11 @@ void convg_kernel(IflConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = v[e] * a.beta; v[e] = v[e] + r[e]; }
             }
+            if (a.mask && c >= a.mask_c0) {
+                f32x4 m = *(const f32x4*)(a.mask + opix * a.mask_stride + a.mask_off + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * a.mask_slope;
+            }
             *(f32x4*)(outp + opix * a.out_stride + a.out_off + c) = v;
         }
 }

@@ -157,7 +157,7 @@ struct IflWs {
 // ---- generic convolution (convg.hip) ------------------------------------------------------------------------------
 // Input channels = up to two sources read one after the other (each a channel range, a multiple of 32 wide, of a ringed
 // channels-last buffer); output = `cout` channels (multiple of 32) written at channel out_off of a ringed buffer.
-//   v = conv + bias;  act (1 LeakyReLU 0.2, 2 ReLU);  if res1: v = v*alpha + res1;  if res2: v = v*beta + res2.
+//   v = conv + bias;  act (1 LeakyReLU 0.2, 2 ReLU);  if res1: v = v*alpha + res1;  if res2: v = v*beta + res2;  if mask: see below.
 // Weights: [group of 32 outputs][chunk of 32 inputs][tap][kq][lane half h][lane i][e] =
 //          W[out = group*32 + i][in = chunk*32 + kq*8 + h*4 + e][tap].
 struct IflConvArgs {
@@ -170,6 +170,10 @@ struct IflConvArgs {
     // batched form: nz independent problems of one shape in one launch (blockIdx.y = z * Bz + image), operands z_* floats apart
     int nz, Bz;
     int64_t z_src[2], z_w, z_bias, z_out, z_res1;
+    // last: output channels c >= mask_c0 are multiplied by LeakyReLU's derivative at the activation mask[pixel][mask_off + c]
+    // (v if it is > 0, else v * mask_slope): the data gradient of a dense block's convolution completes the gradient wrt
+    // the newest 32 channels it reads, which passes through that activation before the next convolution uses it
+    const float* mask; int mask_stride, mask_off, mask_c0; float mask_slope;
 };
 int ifl_k_convg(const IflConvArgs& a, int B, hipStream_t st);
 int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int dys, int dyoff, int cout, float* dW,

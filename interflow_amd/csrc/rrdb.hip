@@ -320,3 +320,311 @@ extern "C" int ifl_rrdb_encode(const float* params, int nb, const int* block_idx
                            RRDB_NF, 0, p4.h, p4.w))) return rc;
     return 0;
 }
+
+// ======================================================================================================================
+// The encoder with gradients (train.py:72,129 with network_G.train_RRDB, RRDBGlowNet_arch.py:26-33): forward that keeps
+// every dense block's buffer, and a backward that walks the blocks in reverse -- per convolution one data-gradient launch
+// (convg with the transposed, flipped weights, accumulating into the block's gradient buffer; LeakyReLU's derivative of the
+// newest 32 channels in its epilogue) -- followed by the weight gradients of the same convolution of all 3 nb blocks in one
+// launch each.  Only what feeds 'fea_up1' / 'fea_up2' (the maps the flow reads) is computed; upconv2, HRconv and conv_last
+// receive no gradient from the flow's loss.
+//   D[q], q = 0..3nb : dense buffer of block q ([0,64) = its input = the output of block q-1, [64,192) = x1..x4); D[3nb][0,64) = fea
+//   G[q]             : gradients of the same; E[q] = gradient wrt x5 of block q (64 channels)
+namespace {
+
+struct TrainWs {
+    float *s2d, *D, *G, *E, *last, *dlast, *up2in, *f2, *df2, *dup2in;
+    int64_t dstride, estride, gbytes, bytes;
+};
+
+TrainWs train_layout(void* base, int B, int H, int W, int nb)
+{
+    TrainWs e{};
+    int64_t p = 0;
+    auto take = [&](int64_t nfloats) { int64_t r = p; p += (nfloats * 4 + 255) / 256 * 256; return (float*)((char*)base + r); };
+    const int64_t r4 = (int64_t)B * (H / 4 + 2) * (W / 4 + 2), r2 = (int64_t)B * (H / 2 + 2) * (W / 2 + 2);
+    const int nq = 3 * nb;
+    e.dstride = (r4 * RRDB_DENSE + 63) / 64 * 64;
+    e.estride = (r4 * RRDB_NF + 63) / 64 * 64;
+    e.s2d = take(r4 * RRDB_NF);
+    e.D = take(e.dstride * (nq + 1));
+    e.G = take(e.dstride * (nq + 1));
+    e.gbytes = e.dstride * (nq + 1) * 4;
+    e.E = take(e.estride * nq);
+    e.last = take(r4 * RRDB_NF);
+    e.dlast = take(r4 * RRDB_NF);
+    e.up2in = take(r2 * RRDB_NF);
+    e.f2 = take(r2 * RRDB_NF);
+    e.df2 = take(r2 * RRDB_NF);
+    e.dup2in = take(r2 * RRDB_NF);
+    e.bytes = p;
+    return e;
+}
+
+// NCHW gradient [B][Ctot][f hs][f ws], channels coff + [0, 64) -> ringed plane [B][hs+2][ws+2][stride] at channel off: the
+// adjoint of ring_to_nchw_resize_kernel for equal sizes (f = 1) and for the nearest x2 resize (f = 2: the four children of a
+// pixel are added).  mask (optional, ringed, 64 channels): LeakyReLU(0.2)'s derivative at that activation.  accumulate: +=.
+__global__ __launch_bounds__(256)
+void nchw_to_ring_kernel(const float* __restrict__ src, int Ctot, int coff, int f, float* __restrict__ dst, int stride, int off,
+                         int B, int hs, int ws, const float* __restrict__ mask, int accumulate)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * hs * ws * RRDB_NF) return;
+    const int c = e & 63; int64_t t = e >> 6; const int x = t % ws; t /= ws; const int y = t % hs; const int b = t / hs;
+    const int ho = f * hs, wo = f * ws;
+    const float* s = src + (((int64_t)b * Ctot + coff + c) * ho + f * y) * wo + f * x;
+    float v = s[0];
+    if (f == 2) v = (v + s[1]) + (s[wo] + s[wo + 1]);
+    const int64_t rp = ((int64_t)b * (hs + 2) + y + 1) * (ws + 2) + x + 1;
+    if (mask) v = mask[rp * RRDB_NF + c] > 0.f ? v : v * 0.2f;
+    float* d = dst + rp * stride + off + c;
+    *d = accumulate ? *d + v : v;
+}
+
+// adjoint of up2_ring_kernel: dst[b][y][x] += the four children of src (ringed 64-channel planes)
+__global__ __launch_bounds__(256)
+void down2_add_ring_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * h * w * 16) return;
+    const int q = e & 15; int64_t t = e >> 4; const int x = t % w; t /= w; const int y = t % h; const int b = t / h;
+    const int W2 = 2 * w + 2;
+    const float* s = src + (((int64_t)b * (2 * h + 2) + 2 * y + 1) * W2 + 2 * x + 1) * RRDB_NF + q * 4;
+    const f32x4 a = *(const f32x4*)s, bb = *(const f32x4*)(s + RRDB_NF), c = *(const f32x4*)(s + (int64_t)W2 * RRDB_NF),
+                d = *(const f32x4*)(s + (int64_t)(W2 + 1) * RRDB_NF);
+    float* o = dst + (((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * RRDB_NF + q * 4;
+    f32x4 v = *(f32x4*)o;
+    v = v + ((a + bb) + (c + d));
+    *(f32x4*)o = v;
+}
+
+// A dense block's output y = x5 * 0.2 + x (RRDBNet_arch.py:29), for the third block of an RRDB followed by out * 0.2 + the RRDB's
+// input (:45).  g = the gradient wrt what block q handed on (Gnext[0,64)):  gy = g (or 0.2 g);  E = 0.2 gy;  G[0,64) += gy;
+// third block: Gskip[0,64) += g.  Interior pixels only.
+__global__ __launch_bounds__(256)
+void rdb_out_bwd_kernel(const float* __restrict__ Gnext, float* __restrict__ E, float* __restrict__ G, float* __restrict__ Gskip,
+                        int B, int h, int w)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * h * w * 16) return;
+    const int q = e & 15; int64_t t = e >> 4; const int x = t % w; t /= w; const int y = t % h; const int b = t / h;
+    const int64_t rp = ((int64_t)b * (h + 2) + y + 1) * (w + 2) + x + 1;
+    const f32x4 g = *(const f32x4*)(Gnext + rp * RRDB_DENSE + q * 4);
+    const f32x4 gy = Gskip ? g * 0.2f : g;
+    *(f32x4*)(E + rp * RRDB_NF + q * 4) = gy * 0.2f;
+    f32x4* gp = (f32x4*)(G + rp * RRDB_DENSE + q * 4);
+    *gp = *gp + gy;
+    if (Gskip) {
+        f32x4* sp = (f32x4*)(Gskip + rp * RRDB_DENSE + q * 4);
+        *sp = *sp + g;
+    }
+}
+
+// dst[z][c] = sum over the ringed pixels of src[z][pixel][off + c], c < nch (rings are zero): bias gradients.  Block =
+// (32 channels, problem z); 8 pixel lanes per channel.
+__global__ __launch_bounds__(256)
+void bias_grad_kernel(const float* __restrict__ src, int64_t zstride, int stride, int off, int64_t npix, float* __restrict__ dst,
+                      int64_t dst_zstride)
+{
+    __shared__ float red[8][33];
+    const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const float* s = src + (int64_t)blockIdx.y * zstride + off + blockIdx.x * 32 + c;
+    float a = 0.f;
+    for (int64_t p = l; p < npix; p += 8) a += s[p * stride];
+    red[l][c] = a;
+    __syncthreads();
+    if (l == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][c];
+        dst[(int64_t)blockIdx.y * dst_zstride + blockIdx.x * 32 + c] = t;
+    }
+}
+
+int check_train_shape(int B, int H, int W, int nb, int n_blocks, const int* block_idxs)
+{
+    int rc = check_enc_shape(B, H, W, nb, n_blocks);
+    if (rc) return rc;
+    for (int i = 0; i < n_blocks; ++i)
+        IFL_CHECK_ARG(block_idxs && block_idxs[i] >= 0 && block_idxs[i] < nb && (i == 0 || block_idxs[i] > block_idxs[i - 1]),
+                      IFL_EINVAL, "block indices must be increasing and below nb");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t ifl_rrdb_train_ws_bytes(int B, int H, int W, int nb)
+{
+    int rc = check_enc_shape(B, H, W, nb, 0);
+    if (rc) return rc;
+    return train_layout(nullptr, B, H, W, nb).bytes;
+}
+
+extern "C" int ifl_rrdb_train_ws_init(void* ws, int64_t ws_bytes, int B, int H, int W, int nb, void* stream)
+{
+    int rc = check_enc_shape(B, H, W, nb, 0);
+    if (rc) return rc;
+    IFL_CHECK_ARG(ws != nullptr, IFL_EINVAL, "null workspace");
+    TrainWs e = train_layout(ws, B, H, W, nb);
+    IFL_CHECK_ARG(ws_bytes >= e.bytes, IFL_ESMALLWS, "workspace %lld B < required %lld B", (long long)ws_bytes, (long long)e.bytes);
+    IFL_HIP(hipMemsetAsync(ws, 0, (size_t)ws_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int ifl_rrdb_train_fwd(const float* params, int nb, const int* block_idxs, int n_blocks, void* ws, const float* x,
+                                  float* fea_up1, float* fea_up2, int B, int H, int W, void* stream)
+{
+    int rc = check_train_shape(B, H, W, nb, n_blocks, block_idxs);
+    if (rc) return rc;
+    IFL_CHECK_ARG(params && ws && x && fea_up1, IFL_EINVAL, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    static thread_local ConvDesc d[64 * 15 + 8];
+    conv_table(nb, d, nullptr);
+    TrainWs e = train_layout(ws, B, H, W, nb);
+    const Plane p4 = make_plane(H / 4, W / 4), p2 = make_plane(H / 2, W / 2);
+    auto blocks1d = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    auto Dq = [&](int q) { return e.D + (int64_t)q * e.dstride; };
+    const int nq = 3 * nb;
+
+    hipLaunchKernelGGL(s2d_ring_kernel, blocks1d((int64_t)B * p4.h * p4.w * 3 * 4), dim3(256), 0, st, x, e.s2d, B, 3, H, W);
+    IFL_LAUNCH_CHECK();
+    int ci = 0;
+    if ((rc = ifl_k_convg(conv_args(params, d[ci++], e.s2d, RRDB_NF, Dq(0), RRDB_DENSE, 0, 0, p4), B, st))) return rc;
+    for (int q = 0; q < nq; ++q) {
+        float* X = Dq(q);
+        for (int c = 0; c < 4; ++c)
+            if ((rc = ifl_k_convg(conv_args(params, d[ci++], X, RRDB_DENSE, X, RRDB_DENSE, RRDB_NF + c * RRDB_GC, 1, p4), B, st))) return rc;
+        IflConvArgs a = conv_args(params, d[ci++], X, RRDB_DENSE, Dq(q + 1), RRDB_DENSE, 0, 0, p4);
+        a.res1 = X; a.res1_stride = RRDB_DENSE; a.res1_off = 0; a.alpha = 0.2f;
+        if (q % 3 == 2) { a.res2 = Dq(q - 2); a.res2_stride = RRDB_DENSE; a.res2_off = 0; a.beta = 0.2f; }
+        if ((rc = ifl_k_convg(a, B, st))) return rc;
+    }
+    {
+        IflConvArgs a = conv_args(params, d[ci++], Dq(nq), RRDB_DENSE, e.last, RRDB_NF, 0, 0, p4);
+        a.res1 = Dq(nq); a.res1_stride = RRDB_DENSE; a.res1_off = 0; a.alpha = 1.f;
+        if ((rc = ifl_k_convg(a, B, st))) return rc;
+    }
+    if (fea_up2) {
+        hipLaunchKernelGGL(up2_ring_kernel, blocks1d((int64_t)B * p2.h * p2.w * 16), dim3(256), 0, st, e.last, e.up2in, B, p4.h, p4.w);
+        IFL_LAUNCH_CHECK();
+        if ((rc = ifl_k_convg(conv_args(params, d[ci], e.up2in, RRDB_NF, e.f2, RRDB_NF, 0, 1, p2), B, st))) return rc;
+    }
+    auto emit = [&](const float* src, int cs, const Plane& ps, float* dst, int Ctot, int coff, int ho, int wo) -> int {
+        dim3 grid(ifl_cdiv(ho * wo, 32), ifl_cdiv(RRDB_NF, 32), B);
+        hipLaunchKernelGGL(ring_to_nchw_resize_kernel, grid, dim3(256), 0, st, src, cs, RRDB_NF, ps.h, ps.w, dst, Ctot, coff, ho, wo,
+                           (float)ps.h / (float)ho, (float)ps.w / (float)wo);
+        IFL_LAUNCH_CHECK();
+        return 0;
+    };
+    const int Ctot = RRDB_NF * (1 + n_blocks);
+    if ((rc = emit(e.last, RRDB_NF, p4, fea_up1, Ctot, 0, p4.h, p4.w))) return rc;
+    if (fea_up2 && (rc = emit(e.f2, RRDB_NF, p2, fea_up2, Ctot, 0, p2.h, p2.w))) return rc;
+    for (int i = 0; i < n_blocks; ++i) {
+        const float* blk = Dq(3 * (block_idxs[i] + 1));               // the RRDB's output = the next block's input channels
+        if ((rc = emit(blk, RRDB_DENSE, p4, fea_up1, Ctot, RRDB_NF * (1 + i), p4.h, p4.w))) return rc;
+        if (fea_up2 && (rc = emit(blk, RRDB_DENSE, p4, fea_up2, Ctot, RRDB_NF * (1 + i), p2.h, p2.w))) return rc;
+    }
+    return 0;
+}
+
+// params_t: the convolutions' weights transposed and flipped (IFL_PACK_TRANSPOSED with all padded input channels as outputs) at
+// the same offsets as `params`.  d_params: gradients in the parameters' own order [cout][cin_pad][9] at w_off and the bias
+// gradients at b_off of ifl_rrdb_conv_desc (zero it first: the weight gradients are added with atomics).
+extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* block_idxs, int n_blocks, void* ws, const float* d_up1,
+                                  const float* d_up2, float* d_params, int B, int H, int W, void* stream)
+{
+    int rc = check_train_shape(B, H, W, nb, n_blocks, block_idxs);
+    if (rc) return rc;
+    IFL_CHECK_ARG(params_t && ws && d_params, IFL_EINVAL, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    static thread_local ConvDesc d[64 * 15 + 8];
+    conv_table(nb, d, nullptr);
+    TrainWs e = train_layout(ws, B, H, W, nb);
+    const Plane p4 = make_plane(H / 4, W / 4), p2 = make_plane(H / 2, W / 2);
+    const int64_t r4 = (int64_t)B * p4.ring, r2 = (int64_t)B * p2.ring;
+    auto blocks1d = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    auto Dq = [&](int q) { return e.D + (int64_t)q * e.dstride; };
+    auto Gq = [&](int q) { return e.G + (int64_t)q * e.dstride; };
+    auto Eq = [&](int q) { return e.E + (int64_t)q * e.estride; };
+    const int nq = 3 * nb, Ctot = RRDB_NF * (1 + n_blocks);
+    const int i_trunk = 1 + 5 * nq, i_up1 = i_trunk + 1;
+    const int64_t n4 = (int64_t)B * p4.h * p4.w * RRDB_NF, n2 = (int64_t)B * p2.h * p2.w * RRDB_NF;
+
+    IFL_HIP(hipMemsetAsync(e.G, 0, (size_t)e.gbytes, st));
+    // ---- the outputs' adjoints: 'fea_up1' = (last | blocks), 'fea_up2' = (f2 | blocks resized x2)
+    if (d_up1) hipLaunchKernelGGL(nchw_to_ring_kernel, blocks1d(n4), dim3(256), 0, st, d_up1, Ctot, 0, 1, e.dlast, RRDB_NF, 0, B, p4.h, p4.w, (const float*)nullptr, 0);
+    else IFL_HIP(hipMemsetAsync(e.dlast, 0, (size_t)r4 * RRDB_NF * 4, st));
+    IFL_LAUNCH_CHECK();
+    for (int i = 0; i < n_blocks; ++i) {
+        float* g = Gq(3 * (block_idxs[i] + 1));
+        if (d_up1) hipLaunchKernelGGL(nchw_to_ring_kernel, blocks1d(n4), dim3(256), 0, st, d_up1, Ctot, RRDB_NF * (1 + i), 1, g, RRDB_DENSE, 0, B, p4.h, p4.w, (const float*)nullptr, 1);
+        if (d_up2) hipLaunchKernelGGL(nchw_to_ring_kernel, blocks1d(n4), dim3(256), 0, st, d_up2, Ctot, RRDB_NF * (1 + i), 2, g, RRDB_DENSE, 0, B, p4.h, p4.w, (const float*)nullptr, 1);
+        IFL_LAUNCH_CHECK();
+    }
+    if (d_up2) {   // f2 = lrelu(upconv1(nearest x2 of last))
+        hipLaunchKernelGGL(nchw_to_ring_kernel, blocks1d(n2), dim3(256), 0, st, d_up2, Ctot, 0, 1, e.df2, RRDB_NF, 0, B, p2.h, p2.w, (const float*)e.f2, 0);
+        IFL_LAUNCH_CHECK();
+        IflConvArgs a = conv_args(params_t, d[i_up1], e.df2, RRDB_NF, e.dup2in, RRDB_NF, 0, 0, p2);
+        a.bias = nullptr;
+        if ((rc = ifl_k_convg(a, B, st))) return rc;
+        hipLaunchKernelGGL(down2_add_ring_kernel, blocks1d((int64_t)B * p4.h * p4.w * 16), dim3(256), 0, st, e.dup2in, e.dlast, B, p4.h, p4.w);
+        IFL_LAUNCH_CHECK();
+        if ((rc = ifl_k_wgrad(e.up2in, RRDB_NF, 0, RRDB_NF, e.df2, RRDB_NF, 0, RRDB_NF, d_params + d[i_up1].w_off, RRDB_NF, 0, 9, p2.g, B, st))) return rc;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, e.df2, (int64_t)0, RRDB_NF, 0, r2, d_params + d[i_up1].b_off, (int64_t)0);
+        IFL_LAUNCH_CHECK();
+    }
+    // ---- last = fea + trunk_conv(fea):  G[nq][0,64) (already holding the last block's share) += dlast + trunk_conv^T dlast
+    {
+        IflConvArgs a = conv_args(params_t, d[i_trunk], e.dlast, RRDB_NF, Gq(nq), RRDB_DENSE, 0, 0, p4);
+        a.bias = nullptr;
+        a.res1 = Gq(nq); a.res1_stride = RRDB_DENSE; a.res1_off = 0; a.alpha = 1.f;
+        a.res2 = e.dlast; a.res2_stride = RRDB_NF; a.res2_off = 0; a.beta = 1.f;
+        if ((rc = ifl_k_convg(a, B, st))) return rc;
+        if ((rc = ifl_k_wgrad(Dq(nq), RRDB_DENSE, 0, RRDB_NF, e.dlast, RRDB_NF, 0, RRDB_NF, d_params + d[i_trunk].w_off, RRDB_NF, 0, 9, p4.g, B, st))) return rc;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, e.dlast, (int64_t)0, RRDB_NF, 0, r4, d_params + d[i_trunk].b_off, (int64_t)0);
+        IFL_LAUNCH_CHECK();
+    }
+    // ---- the dense blocks in reverse
+    for (int q = nq - 1; q >= 0; --q) {
+        const bool third = q % 3 == 2;
+        hipLaunchKernelGGL(rdb_out_bwd_kernel, blocks1d((int64_t)B * p4.h * p4.w * 16), dim3(256), 0, st, Gq(q + 1), Eq(q), Gq(q),
+                           third ? Gq(q - 2) : (float*)nullptr, B, p4.h, p4.w);
+        IFL_LAUNCH_CHECK();
+        const int c5 = 1 + 5 * q + 4;
+        for (int c = 4; c >= 0; --c) {                                  // conv5 (c = 4), then conv4 .. conv1
+            const ConvDesc& cd = d[1 + 5 * q + c];                       // forward: cd.cin inputs -> cd.cout outputs
+            ConvDesc t{cd.cout, cd.cin, cd.w_off, cd.b_off};             // its data gradient: cd.cout inputs -> cd.cin outputs
+            if (c == 4) t.cin = RRDB_NF;
+            const float* src = c == 4 ? Eq(q) : Gq(q);
+            IflConvArgs a = conv_args(params_t, t, src, c == 4 ? RRDB_NF : RRDB_DENSE, Gq(q), RRDB_DENSE, 0, 0, p4);
+            if (c < 4) a.src_off[0] = RRDB_NF + c * RRDB_GC;
+            a.bias = nullptr;
+            a.res1 = Gq(q); a.res1_stride = RRDB_DENSE; a.res1_off = 0; a.alpha = 1.f;
+            if (c > 0) { a.mask = Dq(q); a.mask_stride = RRDB_DENSE; a.mask_off = 0; a.mask_c0 = cd.cin - RRDB_GC; a.mask_slope = 0.2f; }
+            if ((rc = ifl_k_convg(a, B, st))) return rc;
+        }
+        (void)c5;
+    }
+    // ---- weight and bias gradients: the same convolution of all blocks in one launch
+    const int64_t rec = d[6].w_off - d[1].w_off;                         // floats between consecutive blocks' records
+    for (int c = 0; c < 4; ++c) {
+        const ConvDesc& cd = d[1 + c];
+        if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, cd.cin, e.G, RRDB_DENSE, RRDB_NF + c * RRDB_GC, RRDB_GC, d_params + cd.w_off, cd.cin, 0, 9,
+                              p4.g, B, st, nq, e.dstride, e.dstride, rec))) return rc;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(1, nq), dim3(256), 0, st, e.G, e.dstride, RRDB_DENSE, RRDB_NF + c * RRDB_GC, r4,
+                           d_params + cd.b_off, rec);
+        IFL_LAUNCH_CHECK();
+    }
+    {
+        const ConvDesc& cd = d[5];
+        if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, RRDB_DENSE, e.E, RRDB_NF, 0, RRDB_NF, d_params + cd.w_off, RRDB_DENSE, 0, 9, p4.g, B, st,
+                              nq, e.dstride, e.estride, rec))) return rc;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, nq), dim3(256), 0, st, e.E, e.estride, RRDB_NF, 0, r4, d_params + cd.b_off, rec);
+        IFL_LAUNCH_CHECK();
+    }
+    // conv_first: space2depth(x) -> D[0][0,64)
+    if ((rc = ifl_k_wgrad(e.s2d, RRDB_NF, 0, RRDB_NF, Gq(0), RRDB_DENSE, 0, RRDB_NF, d_params + d[0].w_off, RRDB_NF, 0, 9, p4.g, B, st))) return rc;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, Gq(0), (int64_t)0, RRDB_DENSE, 0, r4, d_params + d[0].b_off, (int64_t)0);
+    IFL_LAUNCH_CHECK();
+    return 0;
+}

@@ -138,6 +138,9 @@ class RRDBNet(nn.Module):
         return self._forward_hipconv(x, get_steps)
 
 
+RRDB_TRAIN_FUSED = True        # tests switch it off to compare with the convolution-by-convolution evaluation
+
+
 class RRDBGlowNet(nn.Module):
     """RRDBGlowNet_arch.py:16-59,217-246.  The DeFlow-legacy normal_flow/reverse_flow (:81-214) are not called
     by InterFlow's drivers and are not provided."""
@@ -239,7 +242,13 @@ class RRDBGlowNet(nn.Module):
         upn1 = opt_get(self.opt, ['network_G', 'flow', 'fea_up-1']) or False
         if not self._needs_autograd() and concat_on and not upn1:
             return self._rrdb_hip(lr, outputs)
-        # autograd has to reach the encoder's parameters: the differentiable evaluation (every convolution on the HIP kernels)
+        # autograd has to reach the encoder's parameters
+        from . import train_rrdb
+        if RRDB_TRAIN_FUSED and concat_on and train_rrdb.usable(self, lr, outputs):
+            res = train_rrdb.encode(self, lr, outputs)         # forward and backward inside the library (csrc/rrdb.hip)
+            if res is not None:
+                return res
+        # the differentiable evaluation convolution by convolution (every convolution on the HIP kernels)
         if not lr.is_cuda:
             raise hip.InterflowHipError(f"rrdbPreprocessing: tensor is on {lr.device}; there is no CPU path")
         rrdbResults = self.RRDB(lr, get_steps=True)

@@ -150,7 +150,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo",
            "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep",
-           "ifl_adam_table", "ifl_wino4_untile", "ifl_pack_table", "ifl_affine_px_blocks", "ifl_train_level_fwd", "ifl_train_level_bwd", "ifl_train_vg_floats",
+           "ifl_adam_table", "ifl_wino4_untile", "ifl_rrdb_train_ws_bytes", "ifl_rrdb_train_ws_init", "ifl_rrdb_train_fwd", "ifl_rrdb_train_bwd", "ifl_pack_table", "ifl_affine_px_blocks", "ifl_train_level_fwd", "ifl_train_level_bwd", "ifl_train_vg_floats",
            "ifl_train_bulk_conv1", "ifl_wino4_tiles", "ifl_wino4_kmajor", "ifl_wino4_dw", "ifl_conv2d_wgrad_batched", "ifl_conv2d_batched")
 
 K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DEC, K_ANIC = range(7)

@@ -616,3 +616,52 @@ def test_table_adam_matches_torch_adam():
     for p, q in zip(pa, pb):
         assert float((p - q).detach().abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max()))
     assert float(A2.state[pa[0]]["step"]) == 6.0
+
+
+def test_fused_encoder_training_matches_convolution_by_convolution():
+    """train_rrdb (ifl_rrdb_train_fwd / _bwd: the encoder's forward and backward inside the library) against
+    RRDBNet._forward_hipconv (one autograd Function per convolution, ATen glue), which test_rrdb_trainable_* pin to the
+    oracle: the two feature maps and every parameter gradient for a random cotangent; twice (workspace reuse); and inside
+    accumulate_into_grad()."""
+    from interflow_amd import flow_model, train_fused
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    arch = model.arch
+    B, H = 2, 40                                                 # 10x10 and 20x20 planes: partial tiles everywhere
+    g = torch.Generator(device=dev()).manual_seed(3)
+    x = torch.rand(B, 3, H, H, device=dev(), generator=g)
+    w1 = torch.randn(B, 320, H // 4, H // 4, device=dev(), generator=g)
+    w2 = torch.randn(B, 320, H // 2, H // 2, device=dev(), generator=g)
+    prm = dict(arch.RRDB.named_parameters())
+
+    def run(fused):
+        for p in prm.values():
+            p.grad = None
+        flow_model.RRDB_TRAIN_FUSED = fused
+        try:
+            r = arch.rrdbPreprocessing(x, outputs=("fea_up1", "fea_up2"))
+        finally:
+            flow_model.RRDB_TRAIN_FUSED = True
+        ((r["fea_up1"] * w1).sum() + (r["fea_up2"] * w2).sum()).backward()
+        return r["fea_up1"].detach(), r["fea_up2"].detach(), {k: p.grad.clone() for k, p in prm.items() if p.grad is not None}
+    a1, a2, ga = run(False)
+    assert "_rrdb_train_plans" not in arch.__dict__
+    for rnd in range(2):
+        b1, b2, gb = run(True)
+        assert len(arch._rrdb_train_plans) == 1 and not next(iter(arch._rrdb_train_plans.values())).busy
+        assert rel(b1, a1) < 1e-6 and rel(b2, a2) < 1e-6, (rel(b1, a1), rel(b2, a2))
+        assert sorted(ga) == sorted(gb), set(ga) ^ set(gb)
+        worst = max(((k, rel(gb[k], ga[k])) for k in ga), key=lambda t: t[1])
+        print(f"round {rnd}: {len(ga)} encoder gradients, worst {worst[0]}: {worst[1]:.2e}")
+        assert worst[1] < 1e-4, worst
+    for p in prm.values():
+        p.grad = torch.full_like(p, 0.25)
+    r = arch.rrdbPreprocessing(x, outputs=("fea_up1", "fea_up2"))
+    with train_fused.accumulate_into_grad():
+        ((r["fea_up1"] * w1).sum() + (r["fea_up2"] * w2).sum()).backward()
+    for k in ga:
+        assert rel(prm[k].grad - 0.25, ga[k]) < 1e-4, k
+    for k in ("upconv2", "HRconv", "conv_last"):                 # nothing of the flow's loss reaches them
+        assert float((prm[k + ".weight"].grad - 0.25).abs().max()) == 0.0
