@@ -420,8 +420,10 @@ void rdb_out_bwd_kernel(const float* __restrict__ Gnext, float* __restrict__ E, 
     }
 }
 
-// dst[z][c] = sum over the ringed pixels of src[z][pixel][off + c], c < nch (rings are zero): bias gradients.  Block =
-// (32 channels, problem z); 8 pixel lanes per channel.
+// dst[z][c] += sum over the ringed pixels of src[z][pixel][off + c], c < nch (rings are zero): bias gradients.  Block =
+// (32 channels, problem z, pixel slice): 8 pixel lanes per channel, one float atomic per channel and block (dst is zeroed by
+// the caller with the rest of the gradient block).
+constexpr int BIAS_SLICES = 48;
 __global__ __launch_bounds__(256)
 void bias_grad_kernel(const float* __restrict__ src, int64_t zstride, int stride, int off, int64_t npix, float* __restrict__ dst,
                       int64_t dst_zstride)
@@ -429,15 +431,17 @@ void bias_grad_kernel(const float* __restrict__ src, int64_t zstride, int stride
     __shared__ float red[8][33];
     const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
     const float* s = src + (int64_t)blockIdx.y * zstride + off + blockIdx.x * 32 + c;
+    const int64_t per = (npix + gridDim.z - 1) / gridDim.z;
+    const int64_t p0 = (int64_t)blockIdx.z * per, p1 = p0 + per < npix ? p0 + per : npix;
     float a = 0.f;
-    for (int64_t p = l; p < npix; p += 8) a += s[p * stride];
+    for (int64_t p = p0 + l; p < p1; p += 8) a += s[p * stride];
     red[l][c] = a;
     __syncthreads();
     if (l == 0) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += red[i][c];
-        dst[(int64_t)blockIdx.y * dst_zstride + blockIdx.x * 32 + c] = t;
+        atomicAdd(dst + (int64_t)blockIdx.y * dst_zstride + blockIdx.x * 32 + c, t);
     }
 }
 
@@ -570,7 +574,7 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         hipLaunchKernelGGL(down2_add_ring_kernel, blocks1d((int64_t)B * p4.h * p4.w * 16), dim3(256), 0, st, e.dup2in, e.dlast, B, p4.h, p4.w);
         IFL_LAUNCH_CHECK();
         if ((rc = ifl_k_wgrad(e.up2in, RRDB_NF, 0, RRDB_NF, e.df2, RRDB_NF, 0, RRDB_NF, d_params + d[i_up1].w_off, RRDB_NF, 0, 9, p2.g, B, st))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, e.df2, (int64_t)0, RRDB_NF, 0, r2, d_params + d[i_up1].b_off, (int64_t)0);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1, BIAS_SLICES), dim3(256), 0, st, e.df2, (int64_t)0, RRDB_NF, 0, r2, d_params + d[i_up1].b_off, (int64_t)0);
         IFL_LAUNCH_CHECK();
     }
     // ---- last = fea + trunk_conv(fea):  G[nq][0,64) (already holding the last block's share) += dlast + trunk_conv^T dlast
@@ -581,7 +585,7 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         a.res2 = e.dlast; a.res2_stride = RRDB_NF; a.res2_off = 0; a.beta = 1.f;
         if ((rc = ifl_k_convg(a, B, st))) return rc;
         if ((rc = ifl_k_wgrad(Dq(nq), RRDB_DENSE, 0, RRDB_NF, e.dlast, RRDB_NF, 0, RRDB_NF, d_params + d[i_trunk].w_off, RRDB_NF, 0, 9, p4.g, B, st))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, e.dlast, (int64_t)0, RRDB_NF, 0, r4, d_params + d[i_trunk].b_off, (int64_t)0);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1, BIAS_SLICES), dim3(256), 0, st, e.dlast, (int64_t)0, RRDB_NF, 0, r4, d_params + d[i_trunk].b_off, (int64_t)0);
         IFL_LAUNCH_CHECK();
     }
     // ---- the dense blocks in reverse
@@ -611,7 +615,7 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         const ConvDesc& cd = d[1 + c];
         if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, cd.cin, e.G, RRDB_DENSE, RRDB_NF + c * RRDB_GC, RRDB_GC, d_params + cd.w_off, cd.cin, 0, 9,
                               p4.g, B, st, nq, e.dstride, e.dstride, rec))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(1, nq), dim3(256), 0, st, e.G, e.dstride, RRDB_DENSE, RRDB_NF + c * RRDB_GC, r4,
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(1, nq, BIAS_SLICES), dim3(256), 0, st, e.G, e.dstride, RRDB_DENSE, RRDB_NF + c * RRDB_GC, r4,
                            d_params + cd.b_off, rec);
         IFL_LAUNCH_CHECK();
     }
@@ -619,12 +623,12 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         const ConvDesc& cd = d[5];
         if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, RRDB_DENSE, e.E, RRDB_NF, 0, RRDB_NF, d_params + cd.w_off, RRDB_DENSE, 0, 9, p4.g, B, st,
                               nq, e.dstride, e.estride, rec))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, nq), dim3(256), 0, st, e.E, e.estride, RRDB_NF, 0, r4, d_params + cd.b_off, rec);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, nq, BIAS_SLICES), dim3(256), 0, st, e.E, e.estride, RRDB_NF, 0, r4, d_params + cd.b_off, rec);
         IFL_LAUNCH_CHECK();
     }
     // conv_first: space2depth(x) -> D[0][0,64)
     if ((rc = ifl_k_wgrad(e.s2d, RRDB_NF, 0, RRDB_NF, Gq(0), RRDB_DENSE, 0, RRDB_NF, d_params + d[0].w_off, RRDB_NF, 0, 9, p4.g, B, st))) return rc;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1), dim3(256), 0, st, Gq(0), (int64_t)0, RRDB_DENSE, 0, r4, d_params + d[0].b_off, (int64_t)0);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1, BIAS_SLICES), dim3(256), 0, st, Gq(0), (int64_t)0, RRDB_DENSE, 0, r4, d_params + d[0].b_off, (int64_t)0);
     IFL_LAUNCH_CHECK();
     return 0;
 }

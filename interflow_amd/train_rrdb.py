@@ -125,8 +125,13 @@ class _EncoderFn(torch.autograd.Function):
                                            hip._ptr(g2), hip._ptr(plan.dpar), plan.B, plan.H, plan.W, hip._stream()), "ifl_rrdb_train_bwd")
             direct = TF._direct_grad and all(p.grad is not None and p.grad.dtype == torch.float32 for p in plan.params)
             if direct:
-                # (conv_first's weight gradient is a strided view of its padded block: the multi-tensor add takes it as it is)
-                torch._foreach_add_([p.grad for p in plan.params], plan.views)
+                # one multi-tensor add for the contiguous views; conv_first's weight gradient is a strided view of its padded
+                # block (a single non-contiguous tensor would send the whole list down the one-launch-per-tensor path)
+                dense = [(p.grad, v) for p, v in zip(plan.params, plan.views) if v.is_contiguous() and p.grad.is_contiguous()]
+                torch._foreach_add_([a for a, _ in dense], [b for _, b in dense])
+                for p, v in zip(plan.params, plan.views):
+                    if not (v.is_contiguous() and p.grad.is_contiguous()):
+                        p.grad.add_(v)
                 grads = [None] * len(plan.params)
             else:
                 grads = [v.clone() for v in plan.views]
