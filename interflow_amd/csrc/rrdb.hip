@@ -10,6 +10,7 @@
 //                                                             the key's own 64 channels -> 320-channel NCHW tensors
 // All convolutions run through convg.hip.  Buffers are ringed channels-last planes in a caller-owned workspace.
 #include "ifl_common.h"
+#include <mutex>
 
 #define RRDB_NF 64
 #define RRDB_GC 32
@@ -445,6 +446,26 @@ void bias_grad_kernel(const float* __restrict__ src, int64_t zstride, int stride
     }
 }
 
+// The weight gradients only produce parameter gradients: they run on a library-owned second stream per device, in slices of
+// blocks, beside the sequential chain of small data-gradient launches that is still working on the earlier blocks.
+struct EncFork { hipStream_t aux = nullptr; hipEvent_t ev[8] = {}; hipEvent_t join = nullptr; std::mutex mu; };
+EncFork g_encfork[IFL_MAX_DEVICES];
+
+int enc_fork(EncFork** out)
+{
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    IFL_CHECK_ARG(dev >= 0 && dev < IFL_MAX_DEVICES, IFL_ENOTSUP, "device %d", dev);
+    EncFork& f = g_encfork[dev];
+    if (!f.aux) {
+        IFL_HIP(hipStreamCreateWithFlags(&f.aux, hipStreamNonBlocking));
+        for (auto& e : f.ev) IFL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        IFL_HIP(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+    }
+    *out = &f;
+    return 0;
+}
+
 int check_train_shape(int B, int H, int W, int nb, int n_blocks, const int* block_idxs)
 {
     int rc = check_enc_shape(B, H, W, nb, n_blocks);
@@ -588,17 +609,43 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         hipLaunchKernelGGL(bias_grad_kernel, dim3(2, 1, BIAS_SLICES), dim3(256), 0, st, e.dlast, (int64_t)0, RRDB_NF, 0, r4, d_params + d[i_trunk].b_off, (int64_t)0);
         IFL_LAUNCH_CHECK();
     }
-    // ---- the dense blocks in reverse
+    // ---- the dense blocks in reverse; after each slice of blocks, its weight and bias gradients (the same convolution of all
+    // the slice's blocks in one launch) on the second stream
+    EncFork* fk = nullptr;
+    if ((rc = enc_fork(&fk))) return rc;
+    std::lock_guard<std::mutex> lock(fk->mu);
+    const int64_t rec = d[6].w_off - d[1].w_off;                         // floats between consecutive blocks' records
+    auto slice_wgrads = [&](int q0, int q1, hipStream_t ws_) -> int {
+        const int nz = q1 - q0;
+        const float* Dz = e.D + (int64_t)q0 * e.dstride;
+        const float* Gz = e.G + (int64_t)q0 * e.dstride;
+        const float* Ez = e.E + (int64_t)q0 * e.estride;
+        float* dp = d_params + (int64_t)q0 * rec;
+        for (int c = 0; c < 4; ++c) {
+            const ConvDesc& cd = d[1 + c];
+            if (int r = ifl_k_wgrad(Dz, RRDB_DENSE, 0, cd.cin, Gz, RRDB_DENSE, RRDB_NF + c * RRDB_GC, RRDB_GC, dp + cd.w_off, cd.cin, 0, 9,
+                                    p4.g, B, ws_, nz, e.dstride, e.dstride, rec)) return r;
+            hipLaunchKernelGGL(bias_grad_kernel, dim3(1, nz, BIAS_SLICES), dim3(256), 0, ws_, Gz, e.dstride, RRDB_DENSE, RRDB_NF + c * RRDB_GC, r4,
+                               dp + cd.b_off, rec);
+            IFL_LAUNCH_CHECK();
+        }
+        const ConvDesc& cd = d[5];
+        if (int r = ifl_k_wgrad(Dz, RRDB_DENSE, 0, RRDB_DENSE, Ez, RRDB_NF, 0, RRDB_NF, dp + cd.w_off, RRDB_DENSE, 0, 9, p4.g, B, ws_,
+                                nz, e.dstride, e.estride, rec)) return r;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, nz, BIAS_SLICES), dim3(256), 0, ws_, Ez, e.estride, RRDB_NF, 0, r4, dp + cd.b_off, rec);
+        IFL_LAUNCH_CHECK();
+        return 0;
+    };
+    const int nslices = nq >= 12 ? 4 : 1;
+    int hi = nq, slice = 0;
     for (int q = nq - 1; q >= 0; --q) {
         const bool third = q % 3 == 2;
         hipLaunchKernelGGL(rdb_out_bwd_kernel, blocks1d((int64_t)B * p4.h * p4.w * 16), dim3(256), 0, st, Gq(q + 1), Eq(q), Gq(q),
                            third ? Gq(q - 2) : (float*)nullptr, B, p4.h, p4.w);
         IFL_LAUNCH_CHECK();
-        const int c5 = 1 + 5 * q + 4;
         for (int c = 4; c >= 0; --c) {                                  // conv5 (c = 4), then conv4 .. conv1
             const ConvDesc& cd = d[1 + 5 * q + c];                       // forward: cd.cin inputs -> cd.cout outputs
             ConvDesc t{cd.cout, cd.cin, cd.w_off, cd.b_off};             // its data gradient: cd.cout inputs -> cd.cin outputs
-            if (c == 4) t.cin = RRDB_NF;
             const float* src = c == 4 ? Eq(q) : Gq(q);
             IflConvArgs a = conv_args(params_t, t, src, c == 4 ? RRDB_NF : RRDB_DENSE, Gq(q), RRDB_DENSE, 0, 0, p4);
             if (c < 4) a.src_off[0] = RRDB_NF + c * RRDB_GC;
@@ -607,24 +654,23 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
             if (c > 0) { a.mask = Dq(q); a.mask_stride = RRDB_DENSE; a.mask_off = 0; a.mask_c0 = cd.cin - RRDB_GC; a.mask_slope = 0.2f; }
             if ((rc = ifl_k_convg(a, B, st))) return rc;
         }
-        (void)c5;
+        // a slice boundary: the blocks [q, hi) are complete (the third block of an RRDB also wrote into G[q - 2], whose own
+        // chain has not started: slices end on RRDB boundaries, q % 3 == 0)
+        const int lo = nq * (nslices - 1 - slice) / nslices / 3 * 3;
+        if (q == lo && q < hi) {
+            if (nslices == 1) { if ((rc = slice_wgrads(q, hi, st))) return rc; }
+            else {
+                IFL_HIP(hipEventRecord(fk->ev[slice], st));
+                IFL_HIP(hipStreamWaitEvent(fk->aux, fk->ev[slice], 0));
+                if ((rc = slice_wgrads(q, hi, fk->aux))) return rc;
+            }
+            hi = q;
+            ++slice;
+        }
     }
-    // ---- weight and bias gradients: the same convolution of all blocks in one launch
-    const int64_t rec = d[6].w_off - d[1].w_off;                         // floats between consecutive blocks' records
-    for (int c = 0; c < 4; ++c) {
-        const ConvDesc& cd = d[1 + c];
-        if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, cd.cin, e.G, RRDB_DENSE, RRDB_NF + c * RRDB_GC, RRDB_GC, d_params + cd.w_off, cd.cin, 0, 9,
-                              p4.g, B, st, nq, e.dstride, e.dstride, rec))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(1, nq, BIAS_SLICES), dim3(256), 0, st, e.G, e.dstride, RRDB_DENSE, RRDB_NF + c * RRDB_GC, r4,
-                           d_params + cd.b_off, rec);
-        IFL_LAUNCH_CHECK();
-    }
-    {
-        const ConvDesc& cd = d[5];
-        if ((rc = ifl_k_wgrad(e.D, RRDB_DENSE, 0, RRDB_DENSE, e.E, RRDB_NF, 0, RRDB_NF, d_params + cd.w_off, RRDB_DENSE, 0, 9, p4.g, B, st,
-                              nq, e.dstride, e.estride, rec))) return rc;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(2, nq, BIAS_SLICES), dim3(256), 0, st, e.E, e.estride, RRDB_NF, 0, r4, d_params + cd.b_off, rec);
-        IFL_LAUNCH_CHECK();
+    if (nslices > 1) {
+        IFL_HIP(hipEventRecord(fk->join, fk->aux));
+        IFL_HIP(hipStreamWaitEvent(st, fk->join, 0));
     }
     // conv_first: space2depth(x) -> D[0][0,64)
     if ((rc = ifl_k_wgrad(e.s2d, RRDB_NF, 0, RRDB_NF, Gq(0), RRDB_DENSE, 0, RRDB_NF, d_params + d[0].w_off, RRDB_NF, 0, 9, p4.g, B, st))) return rc;
