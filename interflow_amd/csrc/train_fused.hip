@@ -597,54 +597,57 @@ int train_fork(TrainFork** out)
 
 struct Grp { int b0, Bg, idx; int64_t an_blk0, aff_blk0; };    // sample range; first partial-sum block of the group
 
-// one step of one group; cstep = the step's index among the conditional steps (the bulk slab's)
+// one step of one group; cstep = the step's index among the conditional steps (the bulk slab's).
+// Encode (FlowStep.normal_flow, FlowStep.py:114-151):  z_in -affine-> z_a -fAffine-> z_mid -fFeatures-> z_out.
+// Decode (L->decode; reverse_flow, :153-196, the steps listed in the order the decode runs them):
+//   z_in -fFeatures-> z_a -fAffine-> z_mid -affine (the inverse map)-> z_out.
 int fwd_step(const ifl_train_level* L, const Grp& G, int s, int cstep, hipStream_t st)
 {
     const int B = G.Bg, h = L->h, w = L->w, C = L->C;
     const int64_t npx = (int64_t)B * h * w, plane = (int64_t)(h + 2) * (w + 2);
     const int64_t zo = (int64_t)G.b0 * h * w * C, ro = (int64_t)G.b0 * plane;     // offsets of the group in z buffers / ringed pixels
     const int nblk_c = ifl_coupling_blocks(h, w);
-    {
-        const ifl_train_step& S = L->steps[s];
-        IFL_TRY(affine_fwd(S.z_in + zo, S.z_a + zo, S.M, S.c, npx, C, st));
-        if (!S.cond) return 0;
-        for (int i = 0; i < 2; ++i) {
-            const ifl_train_net& N = S.net[i];
-            const float* zsrc = (i == 0 ? S.z_a : S.z_mid) + zo;
-            float* zdst = (i == 0 ? S.z_mid : S.z_out) + zo;
-            const float* p1 = N.p1 + ro * N.p1_stride;
-            float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
-            const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
-            if (L->f_batched && !N.has_z1) {  // its network ran for all steps before the chain
-                IFL_TRY(ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
-                                         B, h, w, C, st));
-                continue;
+    const ifl_train_step& S = L->steps[s];
+    auto net_fwd = [&](int i, const float* zsrc, float* zdst) -> int {
+        const ifl_train_net& N = S.net[i];
+        const float* p1 = N.p1 + ro * N.p1_stride;
+        float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
+        const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
+        if (L->f_batched && !N.has_z1)        // its network ran for all steps before the chain
+            return ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
+                                    B, h, w, C, st);
+        if (N.has_z1) {
+            float* z1 = (S.z1 ? S.z1 : L->z1ring) + ro * 32;
+            hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, z1, npx, h, w, C, L->ch);
+            IFL_LAUNCH_CHECK();
+            if (L->raw) {                     // z1's taps here, the conditioning part from the bulk slab
+                ifl_conv_desc d = {};
+                d.src[0] = z1; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
+                d.w = N.w1; d.out = N.p1 + ro * 64; d.out_stride = 64; d.cout = 64; d.taps = 9;
+                d.res1 = L->raw + (int64_t)cstep * L->raw_step + ro * 128; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
+                IFL_TRY(ifl_conv2d(&d, B, h, w, st));
+            } else {
+                IFL_TRY(conv(z1, 32, ft, L->ft_ch, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
             }
-            if (N.has_z1) {
-                float* z1 = (S.z1 ? S.z1 : L->z1ring) + ro * 32;
-                hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)((npx * L->ch + 255) / 256)), dim3(256), 0, st, zsrc, z1, npx, h, w, C, L->ch);
-                IFL_LAUNCH_CHECK();
-                if (L->raw) {                 // z1's taps here, the conditioning part from the bulk slab
-                    ifl_conv_desc d = {};
-                    d.src[0] = z1; d.src_stride[0] = 32; d.src_ch[0] = 32; d.nsrc = 1;
-                    d.w = N.w1; d.out = N.p1 + ro * 64; d.out_stride = 64; d.cout = 64; d.taps = 9;
-                    d.res1 = L->raw + (int64_t)cstep * L->raw_step + ro * 128; d.res1_stride = 128; d.res1_off = 0; d.alpha = 1.f; d.beta = 1.f;
-                    IFL_TRY(ifl_conv2d(&d, B, h, w, st));
-                } else {
-                    IFL_TRY(conv(z1, 32, ft, L->ft_ch, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
-                }
-            } else if (!L->raw) {
-                IFL_TRY(conv(ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
-            }
-            IFL_TRY(ifl_k_an_relu_fwd(p1, N.p1_stride, a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
-            IFL_TRY(conv(a1, 64, nullptr, 0, N.w2, nullptr, p2, 64, 1, B, h, w, st));
-            IFL_TRY(ifl_an_relu_fwd(p2, a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
-            IFL_TRY(conv(a2, 64, nullptr, 0, N.w3, N.bias3, hraw, N.hstride, 9, B, h, w, st));
-            IFL_TRY(ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
-                                     B, h, w, C, st));
+        } else if (!L->raw) {
+            IFL_TRY(conv(ft, L->ft_ch, nullptr, 0, N.w1, nullptr, N.p1 + ro * 64, 64, 9, B, h, w, st));
         }
+        IFL_TRY(ifl_k_an_relu_fwd(p1, N.p1_stride, a1, N.an1_bias, N.an1_logs, B, h, w, 64, st));
+        IFL_TRY(conv(a1, 64, nullptr, 0, N.w2, nullptr, p2, 64, 1, B, h, w, st));
+        IFL_TRY(ifl_an_relu_fwd(p2, a2, N.an2_bias, N.an2_logs, B, h, w, 64, st));
+        IFL_TRY(conv(a2, 64, nullptr, 0, N.w3, N.bias3, hraw, N.hstride, 9, B, h, w, st));
+        return ifl_coupling_fwd(zsrc, zdst, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, N.ldpart + (int64_t)G.b0 * nblk_c,
+                                B, h, w, C, st);
+    };
+    if (!S.cond) return affine_fwd(S.z_in + zo, S.z_a + zo, S.M, S.c, npx, C, st);
+    if (!L->decode) {
+        IFL_TRY(affine_fwd(S.z_in + zo, S.z_a + zo, S.M, S.c, npx, C, st));
+        IFL_TRY(net_fwd(0, S.z_a + zo, S.z_mid + zo));
+        return net_fwd(1, S.z_mid + zo, S.z_out + zo);
     }
-    return 0;
+    IFL_TRY(net_fwd(1, S.z_in + zo, S.z_a + zo));
+    IFL_TRY(net_fwd(0, S.z_a + zo, S.z_mid + zo));
+    return affine_fwd(S.z_mid + zo, S.z_out + zo, S.M, S.c, npx, C, st);
 }
 
 // one step of one group; *gp = the gradient wrt the step's output on entry, wrt its input on return
@@ -654,60 +657,66 @@ int bwd_step(const ifl_train_level* L, const Grp& G, int s, const float** gp, co
     const int64_t npx = (int64_t)B * h * w, plane = (int64_t)(h + 2) * (w + 2);
     const int64_t zo = (int64_t)G.b0 * h * w * C, ro = (int64_t)G.b0 * plane;
     const int nblk_c = ifl_coupling_blocks(h, w);
-    const float* g = *gp;
     if (dld) dld += G.b0;
-    {
-        const ifl_train_step& S = L->steps[s];
-        if (S.cond) {
-            for (int i = 1; i >= 0; --i) {
-                const ifl_train_net& N = S.net[i];
-                const float* zsrc = (i == 0 ? S.z_a : S.z_mid) + zo;
-                float* dzn = L->dz[i] + zo;             // gradient wrt this coupling's input
-                float* dh = (N.dh ? N.dh : L->dh[i]) + ro * N.hstride;
-                float* da = L->d64[0] + ro * 64;
-                float* dp = (N.dp2 ? N.dp2 : L->d64[1]) + ro * 64;  // gradient wrt the 1x1 convolution's output
-                float* dp1 = (N.dp1 ? N.dp1 : L->d64[1]) + ro * 64; // gradient wrt the first convolution's output
-                const float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
-                const float* p1 = N.p1 + ro * N.p1_stride;
-                const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
-                const int64_t co = (int64_t)G.b0 * nblk_c * 2 * N.n;
-                const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
-                IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part + co,
-                                           N.dbias_part + co, B, h, w, C, st));
-                if (L->f_batched && !N.has_z1) { g = dzn; continue; }     // its network's backward runs for all steps after the chain
-                // Conv2dZeros 3x3: a2 -> hraw
-                if (wg) IFL_TRY(ifl_conv2d_wgrad(a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
-                IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
-                IFL_TRY(ifl_an_relu_bwd(p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part + G.an_blk0 * 128, B, h, w, 64, st));
-                // 1x1: a1 -> p2
-                if (wg) IFL_TRY(ifl_conv2d_wgrad(a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
-                IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
-                IFL_TRY(ifl_k_an_relu_bwd(p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part + G.an_blk0 * 128, B, h, w, 64, st));
-                // first 3x3: (z1 | ft) -> p1
-                if (N.has_z1) {
-                    const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
-                    const float* z1 = S.z1 ? S.z1 + ro * 32 : nullptr;
-                    if (!z1) {                          // not kept by the forward: pack it again
-                        hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring + ro * 32, npx, h, w, C, L->ch);
-                        IFL_LAUNCH_CHECK();
-                        z1 = L->z1ring + ro * 32;
-                    }
-                    if (wg) IFL_TRY(ifl_conv2d_wgrad(z1, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
-                    if (wg && !L->skip_ft_wgrad)
-                        IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
-                    IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring + ro * 32, 32, 9, B, h, w, st));
-                    hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring + ro * 32, dzn, npx, h, w, C, L->ch);
-                    IFL_LAUNCH_CHECK();
-                } else if (wg && !L->skip_ft_wgrad) {
-                    IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
-                }
-                g = dzn;
+    const ifl_train_step& S = L->steps[s];
+    // coupling i: g = gradient wrt its output, dzn = gradient wrt its input zsrc (all channels written)
+    auto net_bwd = [&](int i, const float* zsrc, const float* g, float* dzn) -> int {
+        const ifl_train_net& N = S.net[i];
+        float* dh = (N.dh ? N.dh : L->dh[i]) + ro * N.hstride;
+        float* da = L->d64[0] + ro * 64;
+        float* dp = (N.dp2 ? N.dp2 : L->d64[1]) + ro * 64;  // gradient wrt the 1x1 convolution's output
+        float* dp1 = (N.dp1 ? N.dp1 : L->d64[1]) + ro * 64; // gradient wrt the first convolution's output
+        const float *a1 = N.a1 + ro * 64, *p2 = N.p2 + ro * 64, *a2 = N.a2 + ro * 64, *hraw = N.hraw + ro * N.hstride;
+        const float* p1 = N.p1 + ro * N.p1_stride;
+        const float* ft = L->ft ? L->ft + ro * L->ft_ch : nullptr;
+        const int64_t co = (int64_t)G.b0 * nblk_c * 2 * N.n;
+        const bool wg = !L->skip_step_wgrad;    // weight gradients here, or batched by the caller afterwards
+        IFL_TRY(ifl_k_coupling_bwd(zsrc, g, dld, hraw, N.hstride, N.logs3, L->eps, L->branch, N.c0, N.n, dzn, dh, N.dlogs_part + co,
+                                   N.dbias_part + co, B, h, w, C, st));
+        if (L->f_batched && !N.has_z1) return 0;            // its network's backward runs for all steps after the chain
+        // Conv2dZeros 3x3: a2 -> hraw
+        if (wg) IFL_TRY(ifl_conv2d_wgrad(a2, 64, 0, 64, dh, N.hstride, 0, N.hstride, N.dW3, 64, 0, 9, B, h, w, st));
+        IFL_TRY(conv(dh, N.hstride, nullptr, 0, N.w3t, nullptr, da, 64, 9, B, h, w, st));
+        IFL_TRY(ifl_an_relu_bwd(p2, da, dp, N.an2_bias, N.an2_logs, N.an2_part + G.an_blk0 * 128, B, h, w, 64, st));
+        // 1x1: a1 -> p2
+        if (wg) IFL_TRY(ifl_conv2d_wgrad(a1, 64, 0, 64, dp, 64, 0, 64, N.dW2, 64, 0, 1, B, h, w, st));
+        IFL_TRY(conv(dp, 64, nullptr, 0, N.w2t, nullptr, da, 64, 1, B, h, w, st));
+        IFL_TRY(ifl_k_an_relu_bwd(p1, N.p1_stride, da, dp1, N.an1_bias, N.an1_logs, N.an1_part + G.an_blk0 * 128, B, h, w, 64, st));
+        // first 3x3: (z1 | ft) -> p1
+        if (N.has_z1) {
+            const unsigned nb = (unsigned)((npx * L->ch + 255) / 256);
+            const float* z1 = S.z1 ? S.z1 + ro * 32 : nullptr;
+            if (!z1) {                          // not kept by the forward: pack it again
+                hipLaunchKernelGGL(ring_pack_kernel, dim3(nb), dim3(256), 0, st, zsrc, L->z1ring + ro * 32, npx, h, w, C, L->ch);
+                IFL_LAUNCH_CHECK();
+                z1 = L->z1ring + ro * 32;
             }
+            if (wg) IFL_TRY(ifl_conv2d_wgrad(z1, 32, 0, 32, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 0, 9, B, h, w, st));
+            if (wg && !L->skip_ft_wgrad)
+                IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, 32 + L->ft_ch, 1, 9, B, h, w, st));
+            IFL_TRY(conv(dp1, 64, nullptr, 0, N.w1t, nullptr, L->dz1ring + ro * 32, 32, 9, B, h, w, st));
+            hipLaunchKernelGGL(ring_unpack_add_kernel, dim3(nb), dim3(256), 0, st, L->dz1ring + ro * 32, dzn, npx, h, w, C, L->ch);
+            IFL_LAUNCH_CHECK();
+        } else if (wg && !L->skip_ft_wgrad) {
+            IFL_TRY(ifl_conv2d_wgrad(ft, L->ft_ch, 0, L->ft_ch, dp1, 64, 0, 64, N.dW1, L->ft_ch, 0, 9, B, h, w, st));
         }
-        float* out = (s == 0 ? dz_in : L->dz[2 + (s & 1)]) + zo;
-        IFL_TRY(affine_bwd(S.z_in + zo, g, S.M, out, S.dM_part + G.aff_blk0 * (C * C + C), npx, C, st));
-        *gp = out;
+        return 0;
+    };
+    const float* g = *gp;
+    float* out = (s == 0 ? dz_in : L->dz[2 + (s & 1)]) + zo;
+    float* part = S.dM_part + G.aff_blk0 * (C * C + C);
+    if (!S.cond) {
+        IFL_TRY(affine_bwd(S.z_in + zo, g, S.M, out, part, npx, C, st));
+    } else if (!L->decode) {
+        IFL_TRY(net_bwd(1, S.z_mid + zo, g, L->dz[1] + zo));
+        IFL_TRY(net_bwd(0, S.z_a + zo, L->dz[1] + zo, L->dz[0] + zo));
+        IFL_TRY(affine_bwd(S.z_in + zo, L->dz[0] + zo, S.M, out, part, npx, C, st));
+    } else {
+        IFL_TRY(affine_bwd(S.z_mid + zo, g, S.M, L->dz[0] + zo, part, npx, C, st));
+        IFL_TRY(net_bwd(0, S.z_a + zo, L->dz[0] + zo, L->dz[1] + zo));
+        IFL_TRY(net_bwd(1, S.z_in + zo, L->dz[1] + zo, out));
     }
+    *gp = out;
     return 0;
 }
 

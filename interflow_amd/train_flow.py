@@ -205,6 +205,12 @@ def run(fu, src, rrdbResults, logdet, test_input_size, decode):
             out = train_fused.run_encode(fu, src, feats, ld)
             if out is not None:
                 return out
+    if decode and FUSED_LEVELS:
+        from . import train_fused
+        if train_fused.usable(fu, feats) and src.shape[1] == fu.C:
+            out = train_fused.run_decode(fu, src, feats, ld)
+            if out is not None:
+                return out
     z = src.float().permute(0, 2, 3, 1)
     kinds = [k for k, _ in fu._kinds]
     if not decode:

@@ -90,7 +90,7 @@ class IflTrainLevel(Structure):
     _fields_ = [(k, c_int32) for k in ("B", "h", "w", "C", "ch", "nsteps", "branch", "ft_ch", "skip_step_wgrad", "groups")] + \
                [("eps", c_float), ("skip_ft_wgrad", c_int32), ("ft", c_void_p), ("z1ring", c_void_p), ("dz1ring", c_void_p),
                 ("dz", c_void_p * 4), ("dh", c_void_p * 2), ("d64", c_void_p * 2), ("steps", POINTER(IflTrainStep)),
-                ("anp", c_void_p), ("anp_step", c_int64), ("da_all", c_void_p), ("f_batched", c_int32), ("pad3_", c_int32),
+                ("anp", c_void_p), ("anp_step", c_int64), ("da_all", c_void_p), ("f_batched", c_int32), ("decode", c_int32),
                 ("raw", c_void_p), ("raw_step", c_int64)]
 
 
@@ -170,9 +170,10 @@ def _net_params(seq):
 class LevelPlan:
     """Arena, descriptors and re-layout tables of one flow level for one (B, h, w, device)."""
 
-    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True, batched=True, f_batched=True):
+    def __init__(self, steps, B, h, w, C, device, bulk=True, wino_wgrad=True, batched=True, f_batched=True, decode=False):
         L = _lib()
         self.steps, self.B, self.h, self.w, self.C, self.device = list(steps), B, h, w, C, device
+        self.decode = bool(decode)            # steps in the order the decode runs them; couplings before the (inverse) affine map
         self.busy = False
         self.bulk = bool(bulk)
         ns = len(self.steps)
@@ -370,7 +371,9 @@ class LevelPlan:
         self.grad_tab = self._table(grad_rows)
 
         lv = IflTrainLevel()
-        lv.B, lv.h, lv.w, lv.C, lv.ch, lv.nsteps, lv.branch, lv.ft_ch = B, h, w, C, ch, ns, 1, N_RRDB_CH
+        # multReverse (FlowAffineCouplingsAblation.py:164-165): the encode runs the "divide" branch (1), the decode the "multiply" one
+        lv.B, lv.h, lv.w, lv.C, lv.ch, lv.nsteps, lv.branch, lv.ft_ch = B, h, w, C, ch, ns, 0 if self.decode else 1, N_RRDB_CH
+        lv.decode = 1 if self.decode else 0
         lv.eps = self.eps
         lv.groups = self.groups
         lv.z1ring, lv.dz1ring = ptr(self.z1ring), ptr(self.dz1ring)
@@ -614,9 +617,12 @@ class _StackGroups(torch.autograd.Function):
         return (None,) + tuple(out)
 
 
-def _affine_maps(steps, C, pixels):
+def _affine_maps(steps, C, pixels, decode=False):
     """Per step: M = W diag(exp(logs)), c = M bias (ActNorm2d then InvertibleConv1x1), batched over the level's steps; and the
-    level's data-independent log-det  pixels * sum_steps (sum logs + log|det W|)  (FlowActNorms.py:69-85, Permutations.py:76-101)."""
+    level's data-independent log-det  pixels * sum_steps (sum logs + log|det W|)  (FlowActNorms.py:69-85, Permutations.py:76-101).
+    decode: the inverse maps, z' = exp(-logs) (W^-1 z) - bias, i.e. M = diag(exp(-logs)) W^-1, c = -bias, with W^-1 =
+    U^-1 L^-1 P^T from float64 inverses of the triangular factors as the reference (Permutations.py:103-112); the caller
+    subtracts the log-det."""
     dev = steps[0].actnorm.bias.device
     ics = [s.invconv for s in steps]
     if all(ic.LU for ic in ics):
@@ -628,14 +634,22 @@ def _affine_maps(steps, C, pixels):
         l = l_raw * l_mask + eye
         sign_s = torch.stack([ic.sign_s for ic in ics])
         u = u_raw * l_mask.t() + torch.diag_embed(sign_s * torch.exp(log_s))
-        W = torch.matmul(torch.stack([ic.p for ic in ics]), torch.matmul(l, u))
+        P = torch.stack([ic.p for ic in ics])
+        if decode:
+            li = torch.linalg.inv_ex(l.double())[0].float()        # (inv_ex: no error flag read on the host)
+            ui = torch.linalg.inv_ex(u.double())[0].float()
+            W = torch.matmul(ui, torch.matmul(li, P.transpose(1, 2)))      # p^-1 = p^T exactly
+        else:
+            W = torch.matmul(P, torch.matmul(l, u))
         dl = log_s.sum()
     else:
         logs = torch.stack([s.actnorm.logs.reshape(-1) for s in steps])
         bias = torch.stack([s.actnorm.bias.reshape(-1) for s in steps])
         from .train_flow import invconv_weight
-        ws, dls = zip(*(invconv_weight(ic, False) for ic in ics))
+        ws, dls = zip(*(invconv_weight(ic, decode) for ic in ics))
         W, dl = torch.stack(ws), torch.stack(dls).sum()
+    if decode:
+        return W * torch.exp(-logs)[:, :, None], -bias, (logs.sum() + dl) * pixels
     M = W * torch.exp(logs)[:, None, :]
     c = torch.matmul(M, bias[:, :, None]).squeeze(-1)
     return M, c, (logs.sum() + dl) * pixels
@@ -654,9 +668,9 @@ def usable(fu, feats) -> bool:
     return all(c in (12, 48) for k, c in fu._kinds if k != "squeeze")
 
 
-def _plan_for(fu, level, steps, B, h, w, C, device, params):
+def _plan_for(fu, level, steps, B, h, w, C, device, params, decode=False):
     cache = fu.__dict__.setdefault("_train_plans", {})
-    key = (level, B, h, w, C, str(device), F_BATCHED, GROUPS, BATCHED_WGRAD, USE_BULK, WINO_WGRAD)
+    key = (level, B, h, w, C, str(device), F_BATCHED, GROUPS, BATCHED_WGRAD, USE_BULK, WINO_WGRAD, bool(decode))
     plans = cache.setdefault(key, [])
     plans[:] = [p for p in plans if p.matches(params)]             # parameters moved (.to(), load): drop stale descriptors
     for p in plans:
@@ -664,7 +678,7 @@ def _plan_for(fu, level, steps, B, h, w, C, device, params):
             return p
     if len(plans) >= MAX_PLANS_PER_SHAPE:
         return None
-    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD, batched=BATCHED_WGRAD, f_batched=F_BATCHED)
+    p = LevelPlan(steps, B, h, w, C, device, bulk=USE_BULK, wino_wgrad=WINO_WGRAD, batched=BATCHED_WGRAD, f_batched=F_BATCHED, decode=decode)
     plans.append(p)
     return p
 
@@ -710,4 +724,49 @@ def run_encode(fu, src, feats, ld):
             return None
         z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, z, M, c, *params)
         ld = ld + ld_lv + ld_const
+    return z.permute(0, 3, 1, 2).contiguous(), ld
+
+
+def run_decode(fu, z_nchw, feats, ld):
+    """FlowUpsamplerNet.decode (FlowUpsamplerNet.py:271-304) with gradients on the level drivers: the levels from the last to
+    the first, each level's steps in reverse with the couplings before the inverse affine map (FlowStep.py:153-196), an
+    unsqueeze after each level.  z_nchw: [B, C_last, h, w]; feats: {level: NCHW conditioning map}.  Returns (x NCHW, logdet)
+    or None when no arena is free."""
+    from .train_flow import unsqueeze_cl
+    levels, cur = [], None
+    for layer, (kind, C) in zip(fu.layers, fu._kinds):
+        if kind == "squeeze":
+            cur = []
+            levels.append((C, cur))
+        else:
+            cur.append(layer)
+    z = z_nchw.float().permute(0, 2, 3, 1)
+    B, h, w = z.shape[0], z.shape[1], z.shape[2]
+    assert z.shape[3] == levels[-1][0], (tuple(z.shape), levels[-1][0])
+    plans = []
+    for lv in range(len(levels), 0, -1):
+        C, steps = levels[lv - 1]
+        steps = list(reversed(steps))
+        pcache = fu.__dict__.setdefault("_train_params_dec", {})
+        if lv not in pcache:
+            pcache[lv] = [p for s in steps if hasattr(s, "affine") for name in ("fAffine", "fFeatures") for p in _net_params(getattr(s.affine, name))]
+        params = pcache[lv]
+        plan = _plan_for(fu, lv, steps, B, h, w, C, z.device, params, decode=True)
+        if plan is None:
+            return None
+        plans.append((plan, params, steps, C, h, w, lv))
+        h, w = h * 2, w * 2
+    maps = [_affine_maps(steps, C, h_ * w_, decode=True) for _, _, steps, C, h_, w_, _ in plans]
+    for (plan, params, steps, C, h_, w_, lv), (M, c, ld_const) in zip(plans, maps):
+        ft = feats.get(lv)
+        ft_ring = None
+        if any(plan.cond):
+            assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h_, w_), (lv, None if ft is None else tuple(ft.shape))
+            ft_ring = T.to_ring(ft.detach().float())
+        ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
+        if ft_src is not None and not plan.can_ft_grad:
+            return None
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, z.contiguous(), M, c, *params)
+        ld = ld + ld_lv - ld_const
+        z = unsqueeze_cl(z)
     return z.permute(0, 3, 1, 2).contiguous(), ld

@@ -275,8 +275,9 @@ def test_winograd_first_convolutions_at_patch_size():
     assert rel(z, z0) < 2e-5 and rel(ld, ld0) < 1e-5
     plans = model.arch.flowUpsamplerNet._train_plans
     for lv in (1, 2):
-        pb = next(v[0] for k, v in plans.items() if k[0] == lv and k[-2] and not k[-1])      # bulk forward, direct weight gradient
-        pd = next(v[0] for k, v in plans.items() if k[0] == lv and not k[-2])                # direct forward
+        # plan keys end with (..., USE_BULK, WINO_WGRAD, decode)
+        pb = next(v[0] for k, v in plans.items() if k[0] == lv and k[-3] and not k[-2])      # bulk forward, direct weight gradient
+        pd = next(v[0] for k, v in plans.items() if k[0] == lv and not k[-3])                # direct forward
         want_a, want_f = pd.act[:, 0, 0, :, 1:-1, 1:-1], pd.act[:, 1, 0, :, 1:-1, 1:-1]
         ea = rel(pb.act[:, 0, 0, :, 1:-1, 1:-1], want_a)                                     # fAffine: z1 taps + slab[0:64]
         ef = rel(pb.raw[:, :, 1:-1, 1:-1, 64:], want_f)                                      # fFeatures: slab[64:128]
@@ -289,31 +290,45 @@ def test_winograd_first_convolutions_at_patch_size():
 
 
 def test_decode_with_gradients_vs_oracle():
-    """The gradient-enabled decode (train.py:94, the LR-consistency branch) against CPU autograd of the oracle."""
+    """The gradient-enabled decode (train.py:94, the LR-consistency branch) against CPU autograd of the oracle: on the level
+    drivers (train_fused.run_decode) and on the layer-by-layer path -- image, log-det, the gradient wrt the latent and wrt
+    EVERY flow parameter.  The bound per tensor is loose (ReLU inputs near zero switch sides between differently rounded
+    forwards; at 4x4 and 8x8 planes one switch moves a weight gradient by percents), the median over the ~760 tensors is not."""
+    from interflow_amd import train_flow
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)
-    B, H = 1, 16
+    B, H = 2, 16                     # (two samples: the level drivers run them as two groups on two streams)
     zin = torch.randn(B, 48, H // 4, H // 4, generator=torch.Generator().manual_seed(5))
     feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(83, B, H, H).items()}
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in sd_np.items()}
-    keys = [f"flow_upsampler.layers.{i}.{n}" for i, n in ((1, "actnorm.logs"), (3, "affine.fAffine.0.weight"), (20, "invconv.l"),
-                                                          (37, "affine.fFeatures.4.weight"), (37, "affine.fAffine.4.logs"))]
-    for k in keys:
-        sd[k].requires_grad_()
+    leaves = {k: v.requires_grad_() for k, v in sd.items()
+              if v.dtype == torch.float32 and k.startswith("flow_upsampler.layers.") and not k.endswith(".p") and not k.endswith(".sign_s")}
     zr = zin.clone().requires_grad_()
     xr, ldr = O.flow_decode(zr, feats, sd, "flow_upsampler.", torch.zeros(B), H)
     (xr.square().mean() + 1e-3 * ldr.mean()).backward()
     model = InterpFlow(SCALES)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
     model.train().to(dev())
-    zd = zin.to(dev()).requires_grad_()
-    x, ld = model(zd, torch.zeros(B, 3, H, H, device=dev()), reverse=True, lr_enc={k: v.to(dev()) for k, v in feats.items()},
-                  add_gt_noise=False, test_input_size=H)
-    assert rel(x, xr) < 1e-4 and rel(ld, ldr) < 1e-4
-    (x.square().mean() + 1e-3 * ld.mean()).backward()
-    assert rel(zd.grad, zr.grad) < 5e-4
     named = dict(model.named_parameters())
-    for k in keys:
-        assert rel(named[k.replace("flow_upsampler.", "arch.flowUpsamplerNet.")].grad, sd[k].grad) < 5e-4, k
+    fu = model.arch.flowUpsamplerNet
+    for fused in (True, False):
+        model.zero_grad(set_to_none=True)
+        zd = zin.to(dev()).requires_grad_()
+        train_flow.FUSED_LEVELS = fused
+        try:
+            x, ld = model(zd, torch.zeros(B, 3, H, H, device=dev()), reverse=True, lr_enc={k: v.to(dev()) for k, v in feats.items()},
+                          add_gt_noise=False, test_input_size=H)
+        finally:
+            train_flow.FUSED_LEVELS = True
+        if fused:
+            plans = [p for v in fu._train_plans.values() for p in v]
+            assert sum(1 for p in plans if p.decode) == 2, "the decode did not run on the level drivers"
+        assert rel(x, xr) < 1e-4 and rel(ld, ldr) < 1e-4
+        (x.square().mean() + 1e-3 * ld.mean()).backward()
+        errs = sorted((rel(named[k.replace("flow_upsampler.", "arch.flowUpsamplerNet.")].grad, v.grad), k) for k, v in leaves.items() if v.grad is not None)
+        med, worst = errs[len(errs) // 2][0], errs[-1]
+        print(f"decode {'on the level drivers' if fused else 'layer by layer'}: d z {rel(zd.grad, zr.grad):.2e}; {len(errs)} parameter gradients, "
+              f"median {med:.2e}, 95 % {errs[int(len(errs) * 0.95)][0]:.2e}, worst {worst[1]}: {worst[0]:.2e}")
+        assert len(errs) > 700 and rel(zd.grad, zr.grad) < 2e-3 and med < 1e-4 and worst[0] < 0.1, (med, worst)
 
 
 def test_data_dependent_actnorm_init():
@@ -665,3 +680,59 @@ def test_fused_encoder_training_matches_convolution_by_convolution():
         assert rel(prm[k].grad - 0.25, ga[k]) < 1e-4, k
     for k in ("upconv2", "HRconv", "conv_last"):                 # nothing of the flow's loss reaches them
         assert float((prm[k + ".weight"].grad - 0.25).abs().max()) == 0.0
+
+
+def test_fused_level_decode_with_gradients():
+    """The gradient-enabled decode of the LR-consistency term (train.py:94) on the level drivers (train_fused.run_decode:
+    steps in reverse, couplings before the inverse affine map) against the layer-by-layer path of the same module, which
+    test_decode_* pin to the oracle: image, log-det, the gradient wrt the latent, wrt the conditioning features and wrt
+    every parameter."""
+    from interflow_amd import train_flow
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 2, 16
+    feats = {k: torch.from_numpy(v).to(dev()) for k, v in synth.synth_features(82, B, H, H).items()}
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    for m in model.modules():                                     # (no data-dependent initialisation in this test)
+        if hasattr(m, "inited"):
+            m.inited = True
+    g = torch.Generator(device=dev()).manual_seed(9)
+    z0 = torch.randn(B, 48, H // 4, H // 4, device=dev(), generator=g)
+    wx = torch.randn(B, 3, H, H, device=dev(), generator=g)
+    named = dict(model.named_parameters())
+    fu = model.arch.flowUpsamplerNet
+
+    def run(fused, ft_grad):
+        model.zero_grad(set_to_none=True)
+        z = z0.clone().requires_grad_(True)
+        fd = {k: v.clone().requires_grad_(ft_grad) for k, v in feats.items()}
+        train_flow.FUSED_LEVELS = fused
+        try:
+            x, ld = model(z, wx, reverse=True, test_input_size=H, lr_enc=fd, add_gt_noise=False)   # (cond image: only its batch size is read)
+        finally:
+            train_flow.FUSED_LEVELS = True
+        ((x * wx).sum() + ld.sum() * 1e-3).backward()
+        return (x.detach(), ld.detach(), z.grad.clone(), {k: v.grad.clone() for k, v in fd.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in named.items() if p.grad is not None})
+    for ft_grad in (False, True):
+        xa, la, gza, gfa, gpa = run(False, ft_grad)
+        n_before = sum(len(v) for v in fu.__dict__.get("_train_plans", {}).values())
+        xb, lb, gzb, gfb, gpb = run(True, ft_grad)
+        plans = [p for v in fu._train_plans.values() for p in v]
+        assert sum(1 for p in plans if p.decode) == 2 and all(not p.busy for p in plans), "the decode did not run on the level drivers"
+        assert rel(xb, xa) < 1e-5 and rel(lb, la) < 1e-5, (rel(xb, xa), rel(lb, la))
+        # (The two paths round the inverse affine maps differently -- MFMA kernel vs ATen matmul.  With this latent no ReLU input
+        # of the coupling networks sits close enough to zero to switch sides between the two forwards; with 0.7 x this latent
+        # one does, at layers.8.affine.fAffine, and every gradient upstream of it then differs by ~4e-4 between the two paths
+        # while each of them stays within 1e-5 of the oracle on its own forward: test_decode_with_gradients_vs_oracle.)
+        assert sorted(gfa) == sorted(gfb) and (len(gfa) == 2) == ft_grad, (sorted(gfa), sorted(gfb))
+        assert sorted(gpa) == sorted(gpb)
+        worst = max(((k, rel(gpb[k], gpa[k])) for k in gpa), key=lambda t: t[1])
+        med = sorted(rel(gpb[k], gpa[k]) for k in gpa)[len(gpa) // 2]
+        print(f"decode, ft_grad={ft_grad}: {len(gpa)} parameter gradients, median {med:.2e}, worst {worst[0]}: {worst[1]:.2e}; "
+              f"d z {rel(gzb, gza):.2e}; d ft {[f'{rel(gfb[k], gfa[k]):.2e}' for k in gfa]}")
+        assert rel(gzb, gza) < 1e-4, rel(gzb, gza)
+        for k in gfa:
+            assert rel(gfb[k], gfa[k]) < 2e-4, (k, rel(gfb[k], gfa[k]))
+        assert worst[1] < 2e-4 and med < 2e-5, (worst, med)
