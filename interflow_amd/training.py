@@ -174,8 +174,10 @@ class TableAdam(torch.optim.Optimizer):
     (`ifl_adam_table`) over a device table of 4 096-element chunks, instead of the fused multi-tensor form's 36 tensors per
     launch (22 launches of ~43 us for the flow's 770 tensors, to move 230 MB).  Same arithmetic as torch's fused kernel.
     State per parameter as torch's (`step`, `exp_avg`, `exp_avg_sq`: a state dict loads into torch.optim.Adam and back);
-    `step` is one device cell shared by all parameters, so every parameter of the optimizer must receive a gradient in every
-    step (a parameter without .grad raises).  `found_inf` (a 0-dim device tensor set as an attribute, the mechanism of
+    `step` is one device cell shared by all parameters of a group: a parameter whose .grad is None is left untouched, as
+    torch does (the encoder's three convolutions behind 'fea_up4' / 'out' never receive one), but its bias correction
+    follows the group's count, which differs from torch only for a parameter that receives gradients in some steps and none
+    in others.  `found_inf` (a 0-dim device tensor set as an attribute, the mechanism of
     torch's GradScaler and of train_step(host_sync=False)) skips the update on the device, step counter included.
     Parameters are written through raw pointers; their version counters are bumped by hand so that caches keyed on them
     (packed weights) see the update."""
@@ -192,14 +194,13 @@ class TableAdam(torch.optim.Optimizer):
         import ctypes
         import numpy as np
         from . import hip
-        params = group["params"]
-        for p in params:
-            if p.grad is None:
-                raise RuntimeError("TableAdam: a parameter has no gradient (every parameter must receive one in every step)")
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+        key = tuple((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in group["params"])
         ent = self._tables.get(gi)
         if ent is not None and ent["key"] == key:
             return ent
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            return None
         dev = params[0].device
         rows = []
         steps = []
@@ -216,15 +217,16 @@ class TableAdam(torch.optim.Optimizer):
             for o in range(0, n, CH):
                 rows.append((p.data_ptr() + 4 * o, p.grad.data_ptr() + 4 * o, st["exp_avg"].data_ptr() + 4 * o,
                              st["exp_avg_sq"].data_ptr() + 4 * o, min(CH, n - o)))
-        if steps and (min(steps) != max(steps) or len(steps) != len(params)):
-            raise RuntimeError("TableAdam: parameters with different step counts (loaded state of another parameter set)")
+        if steps and min(steps) != max(steps):
+            raise RuntimeError("TableAdam: parameters with different step counts (a state dict of torch.optim.Adam in which some "
+                               "parameters skipped steps): one shared step cell cannot represent it")
         if ent is None:
             cells = torch.full((2,), steps[0] if steps else 0.0, dtype=torch.float32, device=dev)
             ent = {"cells": cells, "cur": 0}
         for p in params:
             self.state[p]["step"] = ent["cells"][ent["cur"]:ent["cur"] + 1].reshape(())     # a view of the live cell
         arr = np.array(rows, dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8")]))
-        ent.update(key=key, table=torch.from_numpy(arr.view(np.uint8).copy()).to(dev), nrows=len(rows))
+        ent.update(key=key, table=torch.from_numpy(arr.view(np.uint8).copy()).to(dev), nrows=len(rows), params=params)
         self._tables[gi] = ent
         return ent
 
@@ -242,6 +244,8 @@ class TableAdam(torch.optim.Optimizer):
             if group.get("weight_decay", 0) or group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("TableAdam: weight_decay / amsgrad / maximize")
             ent = self._group_table(gi, group)
+            if ent is None:
+                continue
             cur = ent["cur"]
             cells = ent["cells"]
             b1, b2 = group["betas"]
@@ -251,9 +255,9 @@ class TableAdam(torch.optim.Optimizer):
                                            hip._ptr(found_inf) if found_inf is not None else None, hip._stream()), "ifl_adam_table")
             ent["cur"] = 1 - cur
             live = cells[1 - cur:2 - cur].reshape(())
-            for p in group["params"]:
+            for p in ent["params"]:
                 self.state[p]["step"] = live
-            torch.autograd.graph.increment_version(group["params"])
+            torch.autograd.graph.increment_version(ent["params"])
 
     def state_dict(self):
         """As torch.optim.Adam's: `step` per parameter as a CPU scalar tensor (one device read for the shared cell)."""

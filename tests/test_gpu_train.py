@@ -631,6 +631,11 @@ def test_table_adam_matches_torch_adam():
     for p, q in zip(pa, pb):
         assert float((p - q).detach().abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max()))
     assert float(A2.state[pa[0]]["step"]) == 6.0
+    # a parameter without a gradient is left alone (torch's behaviour)
+    extra = torch.nn.Parameter(torch.ones(5, device=dev))
+    A3 = training.TableAdam(pa + [extra], lr=1e-3)
+    A3.step()
+    assert torch.equal(extra.detach(), torch.ones(5, device=dev)) and "exp_avg" not in A3.state[extra]
 
 
 def test_fused_encoder_training_matches_convolution_by_convolution():
