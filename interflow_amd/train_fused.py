@@ -423,16 +423,18 @@ class LevelPlan:
             self.Yd = torch.zeros(36, N_RRDB_CH, K, **f32)
             self.ut_tab = self._table([dict(r, dst=self.Ut.data_ptr()) for r in self.ut_rows])
 
-    def ft_grad(self):
+    def ft_grad(self, dp1=None):
         """d loss / d ft [B, 320, h, w] from the saved gradients wrt the first convolutions' outputs (call after the level's
-        backward): sum over all (step, network) pairs of the 'same' convolution with the rotated taps, as 36 GEMMs in the
+        backward; dp1: planes of the same shape to use instead, e.g. the sum over several passes): sum over all (step, network) pairs of the 'same' convolution with the rotated taps, as 36 GEMMs in the
         Winograd F(4x4,3x3) domain (a quarter of the direct form's multiplications, one launch instead of 32 convolutions
         and 31 adds of 262 MB tensors)."""
         L = _lib()
         self.ensure_ft_grad()
         self.run_table(self.ut_tab)
         rows = self.Xd.shape[1]
-        hip.check(L.ifl_wino4_kmajor(0, hip._ptr(self.dp1), 64, self.dp1.shape[0], self.dp1[0].numel(), hip._ptr(self.Xd), rows, 0,
+        dp1 = self.dp1 if dp1 is None else dp1
+        assert dp1.shape == self.dp1.shape and dp1.is_contiguous()
+        hip.check(L.ifl_wino4_kmajor(0, hip._ptr(dp1), 64, dp1.shape[0], dp1[0].numel(), hip._ptr(self.Xd), rows, 0,
                                      self.B, self.h, self.w, hip._stream()), "ifl_wino4_kmajor")
         torch.bmm(self.Ut, self.Xd, out=self.Yd)
         dft = torch.empty(self.B, N_RRDB_CH, self.h, self.w, dtype=torch.float32, device=self.device)
@@ -485,6 +487,75 @@ class _Lease:
         self.release()
 
 
+# ---- one d ft product for several passes over the same conditioning features ------------------------------------------------
+# The training step with the LR-consistency term runs four gradient-enabled passes (three encodes, one decode) over the same
+# features with the same weights, and d ft is linear in the saved first-convolution gradients: inside `shared_ft_grad()` every
+# pass adds its dp1 planes into an accumulator owned by a hub node that sits between the features and the passes; autograd
+# runs the hub's backward after all of them, and that is where the ONE Winograd-domain product per level happens.
+_ft_hubs = None
+
+
+class shared_ft_grad:
+    def __enter__(self):
+        global _ft_hubs
+        self.prev, _ft_hubs = _ft_hubs, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _ft_hubs
+        _ft_hubs = self.prev
+
+
+class _FtHub:
+    def __init__(self, ft):
+        self.ft, self.acc, self.plan = ft, None, None              # (ft kept alive: the registry is keyed on its id)
+        self.out, self.tok = _FtHubFn.apply(self, ft)
+
+    def add(self, plan):
+        if self.acc is None:
+            self.acc, self.plan = plan.dp1.clone(), plan           # planes in this plan's (step, network) order, with its U'
+            return
+        assert self.acc.shape == plan.dp1.shape and plan.nc == self.plan.nc
+        d = plan.dp1
+        if plan.decode != self.plan.decode:                        # a decode plan lists the level's steps in reverse
+            d = d.view(plan.nc, 2, *d.shape[1:]).flip(0).reshape(d.shape)
+        self.acc.add_(d)
+
+    def finish(self):
+        if self.acc is None:
+            return None
+        dft = self.plan.ft_grad(self.acc)
+        self.acc = self.plan = None
+        return dft
+
+
+class _FtHubFn(torch.autograd.Function):
+    """Identity on the features plus a one-element token every pass takes as an input and returns a (zero) gradient for: the
+    hub's backward is then scheduled after every pass's backward whatever they return for the features themselves."""
+
+    @staticmethod
+    def forward(ctx, hub, ft):
+        ctx.hub = hub
+        ctx.set_materialize_grads(False)
+        return ft.view_as(ft), torch.zeros(1, dtype=torch.float32, device=ft.device)
+
+    @staticmethod
+    def backward(ctx, g_ft, g_tok):
+        dft = ctx.hub.finish()
+        if dft is None:
+            return None, g_ft
+        return None, dft if g_ft is None else dft + g_ft
+
+
+def _hub_for(ft):
+    if _ft_hubs is None:
+        return None
+    h = _ft_hubs.get(id(ft))
+    if h is None:
+        h = _ft_hubs[id(ft)] = _FtHub(ft)
+    return h
+
+
 MARK = None            # tools/phase_events.py: a callable(name) invoked at the phase boundaries of the level drivers
 
 
@@ -495,9 +566,11 @@ def _mark(name):
 
 class _LevelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, ft_ring, ft_src, z, M_all, c_all, *params):
+    def forward(ctx, plan, ft_ring, ft_src, hub, tok, z, M_all, c_all, *params):
         # ft_ring: the conditioning features as the kernels read them (ringed channels-last, no gradient); ft_src: the NCHW
-        # tensor they were made from when it needs a gradient (a trained encoder), else None
+        # tensor they were made from when it needs a gradient (a trained encoder), else None; hub, tok: inside
+        # `shared_ft_grad()` the hub that computes that gradient for all passes at once, and its token
+        ctx.hub = hub
         L = _lib()
         _mark("before level")
         plan.busy = True
@@ -550,9 +623,14 @@ class _LevelFn(torch.autograd.Function):
                 _pending.add(side)
             else:
                 grads = _LevelFn._weight_phase(plan, ctx.ft_ring, direct)
-            dft = plan.ft_grad() if ctx.needs_input_grad[2] else None
+            dft = gtok = None
+            if ctx.hub is not None:
+                ctx.hub.add(plan)                                          # (the hub's backward makes the product)
+                gtok = torch.zeros(1, **f32)
+            elif ctx.needs_input_grad[2]:
+                dft = plan.ft_grad()
         ctx.lease.release()
-        return (None, None, dft, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
+        return (None, None, dft, None, gtok, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
 
     @staticmethod
     def _weight_phase(plan, ft_ring, direct):
@@ -722,7 +800,11 @@ def run_encode(fu, src, feats, ld):
         ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
         if ft_src is not None and not plan.can_ft_grad:
             return None
-        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, z, M, c, *params)
+        hub = _hub_for(ft) if ft_src is not None else None
+        tok = None
+        if hub is not None:
+            ft_src, tok = hub.out, hub.tok
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, z, M, c, *params)
         ld = ld + ld_lv + ld_const
     return z.permute(0, 3, 1, 2).contiguous(), ld
 
@@ -766,7 +848,11 @@ def run_decode(fu, z_nchw, feats, ld):
         ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
         if ft_src is not None and not plan.can_ft_grad:
             return None
-        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, z.contiguous(), M, c, *params)
+        hub = _hub_for(ft) if ft_src is not None else None
+        tok = None
+        if hub is not None:
+            ft_src, tok = hub.out, hub.tok
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, z.contiguous(), M, c, *params)
         ld = ld + ld_lv - ld_const
         z = unsqueeze_cl(z)
     return z.permute(0, 3, 1, 2).contiguous(), ld

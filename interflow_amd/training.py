@@ -442,6 +442,16 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
         init_actnorm(model, gt, low_res, dist)
     if lr_enc is None:                                                                  # (given: EncoderPrefetcher's features of gt)
         lr_enc = model.arch.rrdbPreprocessing(gt, outputs=FLOW_FEATURES)                # train.py:72 (the maps the L=2 flow reads)
+    from .train_fused import shared_ft_grad
+    import contextlib
+    several = consistency_lambda > 0 and interp is not None                             # four passes over the same features
+    with (shared_ft_grad() if several else contextlib.nullcontext()):
+        return _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, scheduler, step, add_gt_noise,
+                                consistency_lambda, interp, interpolate_weight, lr_enc, late_check, host_sync, dist)
+
+
+def _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, scheduler, step, add_gt_noise, consistency_lambda,
+                     interp, interpolate_weight, lr_enc, late_check, host_sync, dist):
     if late_check:
         z, logdet = model(low_res, gt, lr_enc=lr_enc, add_gt_noise=add_gt_noise, calc_loss=False)    # :73
         nll, ib_loss = model.loss_terms(z, logdet, int(gt.size(2) * gt.size(3)), labels)             # :74

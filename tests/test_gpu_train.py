@@ -529,12 +529,17 @@ def test_encoder_gradients_vs_oracle():
     assert n == 2 * (23 * 15 + 6) and worst[1] < 5e-4, worst
 
 
-def test_full_training_step_against_reference_golden(golden_dir):
+@pytest.mark.parametrize("as_train_step", [False, True, "enc", "hub"])
+def test_full_training_step_against_reference_golden(golden_dir, as_train_step):
     """The whole default training step of the reference -- NLL + ib + 10 x LR-consistency (train.py:72-110), random draws
     pinned -- against outputs and gradients of the reference itself (tests/golden/train_seed0.npz): loss terms, the
-    decoded interpolated image, eight gradient tensors in full and sum / sum-of-squares checksums of all 1456 gradients."""
+    decoded interpolated image, eight gradient tensors in full and sum / sum-of-squares checksums of all 1456 gradients.
+    as_train_step: the way training.train_step runs it -- the encoder's forward and backward inside the library
+    (train_rrdb, two feature maps only) and ONE gradient product towards the features for the four flow passes
+    (train_fused.shared_ft_grad); otherwise the encoder convolution by convolution and one product per pass."""
+    import contextlib
     import os
-    from interflow_amd import training
+    from interflow_amd import training, train_fused
     g = np.load(os.path.join(golden_dir, "train_seed0.npz"))
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)
     assert str(g["digest"]) == synth.state_digest(sd_np)
@@ -549,9 +554,12 @@ def test_full_training_step_against_reference_golden(golden_dir):
     torch.rand = lambda *a, **k: torch.full(a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a, 0.5,
                                             device=k.get("device"))                  # zero noise, as in the fixture
     try:
-        lr_enc = model.arch.rrdbPreprocessing(gt)
-        z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc)
-        cons = training.consistency_loss(model, gt, lr_enc, low_res, lr1, 2, lr2, 4, interpolate_weight=w)
+        lr_enc = model.arch.rrdbPreprocessing(gt, outputs=training.FLOW_FEATURES) if as_train_step in (True, 'enc') else model.arch.rrdbPreprocessing(gt)
+        with (train_fused.shared_ft_grad() if as_train_step in (True, 'hub') else contextlib.nullcontext()) as share:
+            z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc)
+            cons = training.consistency_loss(model, gt, lr_enc, low_res, lr1, 2, lr2, 4, interpolate_weight=w)
+            if as_train_step is True:
+                assert len(train_fused._ft_hubs) == 2 and "_rrdb_train_plans" in model.arch.__dict__, "hubs / fused encoder not used"
     finally:
         torch.rand = real_rand
     loss = nll.mean() + 10 * cons + 1 * (-ll_ib.mean())
