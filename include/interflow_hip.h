@@ -343,7 +343,10 @@ typedef struct ifl_train_level {
                                                     apart: [an1 bias | an1 logs | an2 bias | an2 logs] x 64                   */
     int64_t anp_step;
     float* da_all;                               /* scratch [conditional steps][B][h+2][w+2][64], zero rings                  */
-    int32_t f_batched, decode;                   /* decode: the steps are listed in the order FlowUpsamplerNet.decode runs them and each
+    int32_t f_batched, decode;                   /* f_batched = 2: as 1, but the z-independent network's forward results (raw,
+                                                    a1, p2, a2, hraw of that network) are in the buffers already -- a pass over the same
+                                                    features with the same weights computed them -- and the forward call skips it.
+                                                    decode: the steps are listed in the order FlowUpsamplerNet.decode runs them and each
                                                     runs fFeatures' coupling, fAffine's, then the (inverse) affine map (FlowStep.py:153-196) */
     const float* raw;                            /* optional: ifl_train_bulk_conv1's slabs [conditional step][B][h+2][w+2][128]; then
                                                     w1 of a network with z1 holds the 32 z1 input channels only and p1 = its z1

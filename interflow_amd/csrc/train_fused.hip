@@ -829,7 +829,7 @@ int f_backward(const ifl_train_level* L, hipStream_t st)
 extern "C" int ifl_train_level_fwd(const ifl_train_level* L, void* stream)
 {
     IFL_TRY(check_level(L));
-    if (L->f_batched) IFL_TRY(f_forward(L, (hipStream_t)stream));
+    if (L->f_batched == 1) IFL_TRY(f_forward(L, (hipStream_t)stream));   // 2: its outputs are in the buffers already (the caller copied them from another pass over the same features)
     Groups R;
     IFL_TRY(groups_begin(L, (hipStream_t)stream, &R));
     int rc = 0, cstep = -1;

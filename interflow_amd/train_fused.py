@@ -492,18 +492,24 @@ class _Lease:
 # features with the same weights, and d ft is linear in the saved first-convolution gradients: inside `shared_ft_grad()` every
 # pass adds its dp1 planes into an accumulator owned by a hub node that sits between the features and the passes; autograd
 # runs the hub's backward after all of them, and that is where the ONE Winograd-domain product per level happens.
+# The same context shares the z-independent part of the FORWARD: the first convolutions' conditioning part of both networks
+# (the Winograd bulk launches) and the whole of fFeatures' network depend on the features and the weights only, so the second,
+# third and fourth pass copy them from the first pass's arena (a decode arena lists the steps in reverse) instead of
+# computing them again.
 _ft_hubs = None
+_fwd_donors = None
 
 
 class shared_ft_grad:
     def __enter__(self):
-        global _ft_hubs
-        self.prev, _ft_hubs = _ft_hubs, {}
+        global _ft_hubs, _fwd_donors
+        self.prev = (_ft_hubs, _fwd_donors)
+        _ft_hubs, _fwd_donors = {}, {}
         return self
 
     def __exit__(self, *exc):
-        global _ft_hubs
-        _ft_hubs = self.prev
+        global _ft_hubs, _fwd_donors
+        _ft_hubs, _fwd_donors = self.prev
 
 
 class _FtHub:
@@ -566,7 +572,7 @@ def _mark(name):
 
 class _LevelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, ft_ring, ft_src, hub, tok, z, M_all, c_all, *params):
+    def forward(ctx, plan, ft_ring, ft_src, hub, tok, share_key, z, M_all, c_all, *params):
         # ft_ring: the conditioning features as the kernels read them (ringed channels-last, no gradient); ft_src: the NCHW
         # tensor they were made from when it needs a gradient (a trained encoder), else None; hub, tok: inside
         # `shared_ft_grad()` the hub that computes that gradient for all passes at once, and its token
@@ -583,7 +589,20 @@ class _LevelFn(torch.autograd.Function):
             plan.level.ft = ft_ring.data_ptr() if ft_ring is not None else None
             plan.run_table(plan.pack_tab)
             _mark("pack")
-            if plan.bulk:
+            donor = None
+            if _fwd_donors is not None and plan.f_batched and share_key is not None:
+                donor = _fwd_donors.get(share_key)
+                if donor is None or donor is plan or donor.nc != plan.nc or donor.raw.shape != plan.raw.shape:
+                    _fwd_donors[share_key] = plan
+                    donor = None
+            plan.level.f_batched = 1 if plan.f_batched else 0
+            if donor is not None:
+                flip = (lambda t: t.flip(0)) if donor.decode != plan.decode else (lambda t: t)
+                plan.raw.copy_(flip(donor.raw))
+                plan.act[:, 1, 1:].copy_(flip(donor.act[:, 1, 1:]))        # fFeatures: a1, p2, a2 (its p1 is the slab)
+                plan.hraw[1].copy_(flip(donor.hraw[1]))
+                plan.level.f_batched = 2
+            elif plan.bulk:
                 hip.check(L.ifl_train_bulk_conv1(hip._ptr(ft_ring), hip._ptr(plan.vg), hip._ptr(plan.wx), 2 * WX_FLOATS, plan.nc,
                                                  hip._ptr(plan.raw), plan.raw[0].numel(), plan.B, plan.h, plan.w, hip._stream()),
                           "ifl_train_bulk_conv1")
@@ -630,7 +649,7 @@ class _LevelFn(torch.autograd.Function):
             elif ctx.needs_input_grad[2]:
                 dft = plan.ft_grad()
         ctx.lease.release()
-        return (None, None, dft, None, gtok, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
+        return (None, None, dft, None, gtok, None, dz, dMc[:, :C * C].reshape(-1, C, C), dMc[:, C * C:]) + tuple(grads)
 
     @staticmethod
     def _weight_phase(plan, ft_ring, direct):
@@ -804,7 +823,8 @@ def run_encode(fu, src, feats, ld):
         tok = None
         if hub is not None:
             ft_src, tok = hub.out, hub.tok
-        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, z, M, c, *params)
+        share_key = (id(ft), lv) if (ft is not None and _fwd_donors is not None) else None
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, share_key, z, M, c, *params)
         ld = ld + ld_lv + ld_const
     return z.permute(0, 3, 1, 2).contiguous(), ld
 
@@ -852,7 +872,8 @@ def run_decode(fu, z_nchw, feats, ld):
         tok = None
         if hub is not None:
             ft_src, tok = hub.out, hub.tok
-        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, z.contiguous(), M, c, *params)
+        share_key = (id(ft), lv) if (ft is not None and _fwd_donors is not None) else None
+        z, ld_lv = _LevelFn.apply(plan, ft_ring, ft_src, hub, tok, share_key, z.contiguous(), M, c, *params)
         ld = ld + ld_lv - ld_const
         z = unsqueeze_cl(z)
     return z.permute(0, 3, 1, 2).contiguous(), ld

@@ -558,6 +558,9 @@ def test_full_training_step_against_reference_golden(golden_dir, as_train_step):
         with (train_fused.shared_ft_grad() if as_train_step in (True, 'hub') else contextlib.nullcontext()) as share:
             z, nll, logdet, ll_ib = model(low_res, gt, labels, lr_enc=lr_enc)
             cons = training.consistency_loss(model, gt, lr_enc, low_res, lr1, 2, lr2, 4, interpolate_weight=w)
+            if as_train_step in (True, "hub"):
+                plans = [p for v in model.arch.flowUpsamplerNet._train_plans.values() for p in v]
+                assert sum(1 for p in plans if p.level.f_batched == 2) == 6, "the z-independent forward was not shared (3 of 4 passes, 2 levels)"
             if as_train_step is True:
                 assert len(train_fused._ft_hubs) == 2 and "_rrdb_train_plans" in model.arch.__dict__, "hubs / fused encoder not used"
     finally:
