@@ -553,6 +553,17 @@ class _FtHubFn(torch.autograd.Function):
         return None, dft if g_ft is None else dft + g_ft
 
 
+def _ring_of(ft):
+    """The features as the kernels read them (ringed channels-last); inside `shared_ft_grad()` made once per tensor."""
+    if _fwd_donors is None:
+        return T.to_ring(ft.detach().float())
+    key = ("ring", id(ft))
+    r = _fwd_donors.get(key)
+    if r is None:
+        r = _fwd_donors[key] = (ft, T.to_ring(ft.detach().float()))      # (ft kept alive: keyed on its id)
+    return r[1]
+
+
 def _hub_for(ft):
     if _ft_hubs is None:
         return None
@@ -815,7 +826,7 @@ def run_encode(fu, src, feats, ld):
         ft_ring = None
         if any(plan.cond):
             assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h, w), (lv, None if ft is None else tuple(ft.shape))
-            ft_ring = T.to_ring(ft.detach().float())
+            ft_ring = _ring_of(ft)
         ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
         if ft_src is not None and not plan.can_ft_grad:
             return None
@@ -864,7 +875,7 @@ def run_decode(fu, z_nchw, feats, ld):
         ft_ring = None
         if any(plan.cond):
             assert ft is not None and ft.shape[1] == N_RRDB_CH and tuple(ft.shape[2:]) == (h_, w_), (lv, None if ft is None else tuple(ft.shape))
-            ft_ring = T.to_ring(ft.detach().float())
+            ft_ring = _ring_of(ft)
         ft_src = ft if (ft is not None and ft_ring is not None and ft.requires_grad) else None
         if ft_src is not None and not plan.can_ft_grad:
             return None
