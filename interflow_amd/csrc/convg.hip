@@ -405,11 +405,11 @@ int ifl_k_wgrad(const float* X, int xs, int xoff, int cin, const float* DY, int 
     // 9 KB per 32x32 tile, so more workgroups also mean more atomic traffic.
     const int chunks = cin / 32;
     int gx = 512 / (chunks * nz);
-    if (nz > 1 && gx < 4) gx = 4;
+    if (nz > 1) { if (gx < 4) gx = 4; }                            // batched: the problems fill the chip, keep ONE round
+    else if (gx < 16) gx = 16;
 #ifdef IFL_EXP_GX
     if (getenv("IFL_EXP_GX")) gx = atoi(getenv("IFL_EXP_GX"));
 #endif
-    if (gx < 16) gx = 16;
     if (gx > nwork) gx = nwork;
     dim3 grid(gx, cin / 32, nz), block(256);
 #define IFL_WG(CT, T) hipLaunchKernelGGL((wgrad_kernel<CT, T>), grid, block, 0, st, X, xs, xoff, DY, dys, dyoff, dW, cin_total, ci0, g, B, xz, dyz, dwz)
