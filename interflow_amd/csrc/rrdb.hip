@@ -636,7 +636,8 @@ extern "C" int ifl_rrdb_train_bwd(const float* params_t, int nb, const int* bloc
         IFL_LAUNCH_CHECK();
         return 0;
     };
-    const int nslices = nq >= 12 ? 4 : 1;
+    static const int slices_env = getenv("IFL_RRDB_SLICES") ? atoi(getenv("IFL_RRDB_SLICES")) : 4;    // (1..8)
+    const int nslices = nq >= 12 ? (slices_env < 1 ? 1 : slices_env > 8 ? 8 : slices_env) : 1;
     int hi = nq, slice = 0;
     for (int q = nq - 1; q >= 0; --q) {
         const bool third = q % 3 == 2;
