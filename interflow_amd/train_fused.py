@@ -707,6 +707,7 @@ class _StackGroups(torch.autograd.Function):
     def forward(ctx, k, *params):
         n = len(params) // k
         ctx.k, ctx.n, ctx.params = k, n, params
+        ctx.set_materialize_grads(False)                  # a stack nobody differentiates leaves its parameters' .grad alone
         return tuple(torch.stack(params[g * n:(g + 1) * n]) for g in range(k))
 
     @staticmethod
