@@ -272,7 +272,7 @@ class Split2d(nn.Module):
             dom_y = y_onehot == 1
             if bool(dom_y.any()):
                 noise = torch.randn(mean.shape, device=mean.device)[dom_y] * std
-                eps[dom_y] = eps[dom_y] + self.mean_shift.reshape(1, -1, 1, 1) + torch.matmul(self.cov_shift, noise.T).T
+                eps[dom_y] = eps[dom_y] + self.mean_shift.reshape(1, -1, 1, 1) + torch.matmul(self.cov_shift, noise.permute(3, 2, 1, 0)).permute(3, 2, 1, 0)   # Split.py:101: `.T` of a 4-D tensor
         else:
             eps = hip._dev_f32(eps, "Split2d eps")
         assert eps.shape[0] == y_onehot.shape[0], 'need one class label per datapoint'
@@ -352,9 +352,25 @@ class FlowUpsamplerNet(nn.Module):
                 self.output_shapes.append([-1, self.C, H, W])
                 self._kinds.append(("stepc", self.C))
             correction = 0 if opt_get(opt, ['network_G', 'flow', 'split', 'correct_splits'], False) else 1
-            if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) and level < self.L - correction:
-                raise NotImplementedError("Split2d layers are not scheduled by the fused driver (the shipped config, L=2, creates "
-                                          "none); the operator itself is flow_modules.Split2d")
+            if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) and level < self.L - correction:   # :149-167
+                if opt_get(opt, ['network_G', 'flow', 'split', 'conditional']):
+                    raise NotImplementedError("conditional Split2d: the reference's own driver cannot run it (FlowUpsamplerNet.py:264 "
+                                              "indexes the level's feature TENSOR with the position name)")
+                if opt_get(opt, ['network_G', 'flow', 'split', 'type'], 'Split2d') != 'Split2d':
+                    raise NotImplementedError("split type other than 'Split2d' (the reference creates nothing for it either, :162)")
+                split = Split2d(num_channels=self.C,
+                                logs_eps=opt_get(opt, ['network_G', 'flow', 'split', 'logs_eps']) or 0, position=None,
+                                cond_channels=opt_get(opt, ['network_G', 'flow', 'split', 'cond_channels']) or 0,
+                                consume_ratio=opt_get(opt, ['network_G', 'flow', 'split', 'consume_ratio']) or 0.5, opt=opt)
+                self.layers.append(split)
+                self.output_shapes.append([-1, split.num_channels_pass, H, W])
+                self._kinds.append(("split", self.C))            # C entering the split; half of it goes on
+                self.C = split.num_channels_pass
+        # The fused stack driver (ifl_flow_pass) is built for the shipped layout: channel counts 12 and 48 on two levels.
+        # Anything else -- more levels, Split2d layers: the configurations of general SRFlow / DeFlow checkpoints -- runs layer
+        # by layer on the library's generic kernels (train_flow.run: ifl_conv2d, fused ActNorm+ReLU and coupling kernels,
+        # Split2d on ifl_conv2d + ifl_gaussian_logp), with or without autograd.
+        self._general = any(k == "split" or (k != "squeeze" and c not in (12, 48)) for k, c in self._kinds)
         # dead module the reference registers and never calls (:107-110); kept for the state-dict contract
         n_aff = (len(opt_get(opt, ['network_G', 'flow', 'stackRRDB', 'blocks']) or []) + 1) * 64
         n_f = 2 * 3 * 64 // 2 // 2 if opt_get(opt, ['network_G', 'flow', 'split', 'enable']) else 2 * 3 * 64
@@ -408,6 +424,8 @@ class FlowUpsamplerNet(nn.Module):
             if kind == "squeeze":
                 if not decode:
                     rrdbResults[self.levelToName[level]]      # :239 indexes the dict for every layer
+            elif kind == "split":
+                rrdbResults[self.levelToName[level]]          # :239 / :294 index the dict; an unconditional split reads nothing of it
             else:
                 if decode and level not in range(self.L + 1):
                     raise KeyError(level)                     # level_conditionals[level], :297
@@ -420,10 +438,9 @@ class FlowUpsamplerNet(nn.Module):
 
     def forward(self, gt=None, rrdbResults=None, z=None, epses=None, logdet=0., reverse=False, eps_std=None,
                 y_onehot=None, test_input_size=None):
-        if isinstance(epses, list):
-            raise NotImplementedError("epses lists belong to Split2d layers, which the shipped config never creates")
         if reverse:
-            return self.decode(rrdbResults, z, eps_std, epses=epses, logdet=logdet, y_onehot=y_onehot,
+            epses_copy = [eps for eps in epses] if isinstance(epses, list) else epses     # :206: the caller's list is left alone
+            return self.decode(rrdbResults, z, eps_std, epses=epses_copy, logdet=logdet, y_onehot=y_onehot,
                                test_input_size=test_input_size)
         assert gt is not None
         assert rrdbResults is not None
@@ -444,6 +461,8 @@ class FlowUpsamplerNet(nn.Module):
         recomputes it in each of the passes that `weighted_interpolate_image`, `generate_images.py` and `train.py` run
         over one `lr_enc`).  Returns `rrdbResults` wrapped so that later encode/decode calls with the same batch and
         image size reuse it.  H, W: size of the image the flow encodes (= the decode output)."""
+        if self._general:
+            return rrdbResults                                    # the layer-by-layer evaluation prepares nothing ahead
         enc = self._level_features(rrdbResults, H, test_input_size, decode=False)
         dec = self._level_features(rrdbResults, H, test_input_size, decode=True)
         if set(enc) != set(dec) or any(enc[lv] is not dec[lv] for lv in enc):
@@ -468,10 +487,11 @@ class FlowUpsamplerNet(nn.Module):
             return True
         return any(p.requires_grad for p in self.layers.parameters())
 
-    def _run(self, src, rrdbResults, logdet, test_input_size, decode):
-        if self._needs_autograd(src, rrdbResults):
+    def _run(self, src, rrdbResults, logdet, test_input_size, decode, epses=None, y_onehot=None, eps_std=None):
+        if self._general or self._needs_autograd(src, rrdbResults):
             from . import train_flow
-            out, ld = train_flow.run(self, src, rrdbResults, logdet, test_input_size, decode)
+            out, ld = train_flow.run(self, src, rrdbResults, logdet, test_input_size, decode, epses=epses, y_onehot=y_onehot,
+                                     eps_std=eps_std)
             if decode:
                 assert out.shape[1] == 3
             return out, ld
@@ -503,9 +523,18 @@ class FlowUpsamplerNet(nn.Module):
         return out, ld_out
 
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None, test_input_size=None):
-        return self._run(gt, rrdbResults, logdet, test_input_size, decode=False)
+        """:217-255.  With `epses` a list, every Split2d's eps is appended to it and the list + [z] is returned (:251-255)."""
+        z, logdet = self._run(gt, rrdbResults, logdet, test_input_size, decode=False, epses=epses, y_onehot=y_onehot)
+        if not isinstance(epses, list):
+            return z, logdet
+        epses.append(z)
+        return epses, logdet
 
     def decode(self, rrdbResults, z, eps_std=None, epses=None, logdet=0.0, y_onehot=None, test_input_size=None):
-        sr, logdet = self._run(z, rrdbResults, logdet, test_input_size, decode=True)
+        """:271-304.  A list `epses` supplies z (its last item, :272) and the eps of every Split2d (popped, :306-311); without
+        one a Split2d draws its eps (Split.py:92-103)."""
+        z = epses.pop() if isinstance(epses, list) else z
+        sr, logdet = self._run(z, rrdbResults, logdet, test_input_size, decode=True, epses=epses, y_onehot=y_onehot,
+                               eps_std=eps_std)
         assert sr.shape[1] == 3                                                           # :303
         return sr, logdet

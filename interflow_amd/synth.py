@@ -36,19 +36,24 @@ N_LEVELS = 2         # reference flow_model.py:42
 N_EXTRA = 2          # additionalFlowNoAffine, reference flow_model.py:43
 
 
-def layer_plan(L: int = N_LEVELS, K: int = K_STEPS, extra: int = N_EXTRA, in_ch: int = 3):
+def layer_plan(L: int = N_LEVELS, K: int = K_STEPS, extra: int = N_EXTRA, in_ch: int = 3, split=None):
     """List of (kind, C) in the order of `FlowUpsamplerNet.layers`
     (reference FlowUpsamplerNet.py:94-105): per level squeeze, `extra` no-coupling steps,
-    K conditional steps.  kind in {"squeeze", "step0", "stepc"}; C = channels after the layer."""
+    K conditional steps.  kind in {"squeeze", "step0", "stepc"}; C = channels after the layer.
+    split: None (the shipped configuration creates no Split2d), or {"correct_splits": bool}: a ("split", C entering it) after
+    the steps of every level < L - (0 if correct_splits else 1) (FlowUpsamplerNet.py:149-167); half the channels go on."""
     plan = []
     C = in_ch
-    for _ in range(L):
+    for level in range(1, L + 1):
         C *= 4
         plan.append(("squeeze", C))
         for _ in range(extra):
             plan.append(("step0", C))
         for _ in range(K):
             plan.append(("stepc", C))
+        if split is not None and level < L - (0 if split.get("correct_splits") else 1):
+            plan.append(("split", C))
+            C = C - int(round(C * 0.5))
     return plan
 
 
@@ -92,7 +97,7 @@ def _coupling_net(rng, prefix, cin, cout, in_ms, sd, zeros_std, zeros_bias_std=N
 
 def synth_flow_state(seed: int = 0, L: int = N_LEVELS, K: int = K_STEPS, extra: int = N_EXTRA,
                      ft_rms: float = 1.0, zeros_std: float = 0.02, prefix: str = "",
-                     zeros_bias_std=None) -> "OrderedDict[str, np.ndarray]":
+                     zeros_bias_std=None, split=None) -> "OrderedDict[str, np.ndarray]":
     """State dict of a `FlowUpsamplerNet` (keys `layers.{i}.*`, `f.0.*`), as numpy float32.  zeros_std: std of the
     `Conv2dZeros` weights (how much the coupling scales vary from pixel to pixel); zeros_bias_std: std of their biases
     (how much they vary from channel to channel; default 4 * zeros_std)."""
@@ -102,10 +107,19 @@ def synth_flow_state(seed: int = 0, L: int = N_LEVELS, K: int = K_STEPS, extra: 
     # growth of |z| per conditional step in the encode direction when scale ~= sigmoid(2)+eps
     s_bar = 1.0 / (1.0 + np.exp(-2.0)) + 0.001
     growth = (1.0 / s_bar) * np.sqrt(0.5 * (1.0 + 1.0 / s_bar ** 2))
-    for i, (kind, C) in enumerate(layer_plan(L, K, extra)):
+    for i, (kind, C) in enumerate(layer_plan(L, K, extra, split=split)):
         if kind == "squeeze":
             continue
         p = f"{prefix}layers.{i}."
+        if kind == "split":   # Split2d (Split.py:13-39), unconditional: Conv2dZeros over the passed half, the shifted class prior
+            cons = int(round(C * 0.5))
+            sd[p + "conv.weight"] = _f32(rng.standard_normal((2 * cons, C - cons, 3, 3)) * 0.02)
+            sd[p + "conv.bias"] = _f32(rng.standard_normal(2 * cons) * 0.1)
+            sd[p + "conv.logs"] = _f32(rng.standard_normal((2 * cons, 1, 1)) * 0.1)
+            sd[p + "I"] = _f32(np.eye(cons))
+            sd[p + "mean_shift"] = _f32(rng.standard_normal(cons) * 0.2)
+            sd[p + "cov_shift"] = _f32(np.eye(cons) * 0.7 + rng.standard_normal((cons, cons)) * 0.05)
+            continue
         if first:   # raw pixels U[0,1): centre and whiten like the data-dependent init would
             bias = np.full(C, -0.5) + rng.uniform(-0.02, 0.02, C)
             logs = np.full(C, np.log(1.0 / np.sqrt(1.0 / 12.0))) + rng.uniform(-0.05, 0.05, C)

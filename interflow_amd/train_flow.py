@@ -177,17 +177,35 @@ def unsqueeze_cl(x_cl):
     return x_cl.reshape(B, H, W, C // 4, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, H * 2, W * 2, C // 4)
 
 
-def run(fu, src, rrdbResults, logdet, test_input_size, decode):
-    """FlowUpsamplerNet.encode / decode (FlowUpsamplerNet.py:217-304) as a differentiable graph.  src is NCHW."""
+def _split(layer, z_cl, ld, reverse, epses, y_onehot, eps_std):
+    """A Split2d layer inside the stack (FlowUpsamplerNet.py:243-245,263-269 / :292-295,306-311); the operator works on NCHW."""
+    zn = z_cl.permute(0, 3, 1, 2).contiguous()
+    if y_onehot is None:
+        raise ValueError("Split2d layers need y_onehot: one class label (0 / 1) per sample (Split.py:56-60)")
+    if not reverse:
+        zn, ld, eps = layer(zn, ld, reverse=False, y_onehot=y_onehot)
+        if isinstance(epses, list):
+            epses.append(eps)
+    else:
+        zn, ld = layer(zn, logdet=ld, reverse=True, eps=epses.pop() if isinstance(epses, list) else None, eps_std=eps_std,
+                       y_onehot=y_onehot)
+    return zn.permute(0, 2, 3, 1), ld
+
+
+def run(fu, src, rrdbResults, logdet, test_input_size, decode, epses=None, y_onehot=None, eps_std=None):
+    """FlowUpsamplerNet.encode / decode (FlowUpsamplerNet.py:217-304) layer by layer: a differentiable graph when autograd
+    records, and the evaluation of every configuration the fused stack driver is not built for (more than two levels,
+    Split2d layers; `epses`, `y_onehot`, `eps_std` belong to those).  src is NCHW."""
     from .flow_modules import _as_logdet
     src = hip._dev_f32(src, "flow input") if not src.requires_grad else src
     if not src.is_cuda:
         raise hip.InterflowHipError(f"flow input is on {src.device}; the HIP path needs a GPU tensor (no CPU fallback)")
     B = src.shape[0]
-    H = src.shape[2] * 4 if decode else src.shape[2]
+    H = src.shape[2] << sum(1 for k, _ in fu._kinds if k == "squeeze") if decode else src.shape[2]
     if not decode:
         assert src.shape[1] == 3, src.shape
-        assert src.shape[2] % 4 == 0 and src.shape[3] % 4 == 0, "{}".format((src.shape[2], src.shape[3], 2))
+        n_sq = sum(1 for k, _ in fu._kinds if k == "squeeze")
+        assert src.shape[2] % (1 << n_sq) == 0 and src.shape[3] % (1 << n_sq) == 0, "{}".format((src.shape[2], src.shape[3], 2))
     feats = fu._level_features(rrdbResults, H, test_input_size, decode)
     rings = {}
 
@@ -219,6 +237,8 @@ def run(fu, src, rrdbResults, logdet, test_input_size, decode):
             if kind == "squeeze":
                 z = squeeze_cl(z)
                 level += 1
+            elif kind == "split":
+                z, ld = _split(layer, z, ld, False, epses, y_onehot, eps_std)
             else:
                 z, ld = flow_step(layer, z, ld, False, ft_ring(level) if kind == "stepc" else None)
     else:
@@ -228,6 +248,8 @@ def run(fu, src, rrdbResults, logdet, test_input_size, decode):
             if kind == "squeeze":
                 z = unsqueeze_cl(z)
                 level -= 1
+            elif kind == "split":
+                z, ld = _split(layer, z, ld, True, epses, y_onehot, eps_std)
             else:
                 z, ld = flow_step(layer, z, ld, True, ft_ring(level) if kind == "stepc" else None)
     return z.permute(0, 3, 1, 2).contiguous(), ld

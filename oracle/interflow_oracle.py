@@ -265,8 +265,9 @@ def layer_kinds(sd, pfx):
         if k.startswith(pfx + "layers."):
             idx.add(int(k[len(pfx) + 7:].split(".")[0]))
     n = max(idx) + 1
-    # squeeze layers hold no parameters: every missing index below the max, plus index 0
-    return ["step" if i in idx else "squeeze" for i in range(n)]
+    # squeeze layers hold no parameters: every missing index below the max, plus index 0; a Split2d (multi-level
+    # configurations, FlowUpsamplerNet.py:149-167) is the layer with a `conv.weight` of its own
+    return ["squeeze" if i not in idx else "split" if f"{pfx}layers.{i}.conv.weight" in sd else "step" for i in range(n)]
 
 
 def _static_sizes(kinds, base=160):
@@ -285,8 +286,9 @@ def _level(test_input_size, size):
     return int(np.log(ref / size) / np.log(2))
 
 
-def flow_encode(gt, rrdb_results, sd, pfx, logdet, test_input_size=None, eps=0.001):
-    """FlowUpsamplerNet.encode, FlowUpsamplerNet.py:217-255"""
+def flow_encode(gt, rrdb_results, sd, pfx, logdet, test_input_size=None, eps=0.001, epses=None, y_onehot=None):
+    """FlowUpsamplerNet.encode, FlowUpsamplerNet.py:217-255.  With Split2d layers (unconditional ones: `position` None,
+    :156, :264) each split's eps is appended to `epses` when that is a list, and the list + [z] is returned (:251-255)."""
     kinds = layer_kinds(sd, pfx)
     static = _static_sizes(kinds)
     z = gt
@@ -296,21 +298,35 @@ def flow_encode(gt, rrdb_results, sd, pfx, logdet, test_input_size=None, eps=0.0
         cond = rrdb_results[LEVEL_TO_NAME[level]]          # :239 (indexed for squeeze layers too)
         if kind == "squeeze":
             z = squeeze2d(z, 2)
+        elif kind == "split":                               # :243-245, 263-269
+            z, logdet, e = split2d(z, logdet, False, sd, f"{pfx}layers.{i}.", y_onehot)
+            if isinstance(epses, list):
+                epses.append(e)
         else:
             z, logdet = flow_step(z, logdet, False, cond, sd, f"{pfx}layers.{i}.", eps)
-    return z, logdet
+    if not isinstance(epses, list):
+        return z, logdet
+    epses.append(z)
+    return epses, logdet
 
 
-def flow_decode(z, rrdb_results, sd, pfx, logdet, test_input_size=None, eps=0.001, n_levels=2):
-    """FlowUpsamplerNet.decode, FlowUpsamplerNet.py:271-304"""
+def flow_decode(z, rrdb_results, sd, pfx, logdet, test_input_size=None, eps=0.001, n_levels=2, epses=None, y_onehot=None):
+    """FlowUpsamplerNet.decode, FlowUpsamplerNet.py:271-304; `epses` (a list: the encode's return value) supplies z and the
+    eps of every Split2d, popped from the end of a copy (:206, :272, :306-311)."""
     kinds = layer_kinds(sd, pfx)
     static = _static_sizes(kinds)
+    if isinstance(epses, list):
+        epses = list(epses)
+        z = epses.pop()
     level_conditionals = {lv: rrdb_results[LEVEL_TO_NAME[lv]] for lv in range(n_levels + 1)}   # :278-280
     for i in reversed(range(len(kinds))):
         size = static[i] if test_input_size is None else z.shape[2]
         level = _level(test_input_size, size)
         if kinds[i] == "squeeze":
             z = unsqueeze2d(z, 2)
+        elif kinds[i] == "split":
+            rrdb_results[LEVEL_TO_NAME[level]]              # :294 indexes the dict
+            z, logdet = split2d(z, logdet, True, sd, f"{pfx}layers.{i}.", y_onehot, eps=epses.pop())
         else:
             z, logdet = flow_step(z, logdet, True, level_conditionals[level], sd, f"{pfx}layers.{i}.", eps)
     assert z.shape[1] == 3                                  # :303

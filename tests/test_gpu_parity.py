@@ -158,6 +158,46 @@ def test_split2d_golden(golden_dir, tag, C, cond):
             m(t(g[tag + ".x"]), logdet=0., reverse=False, ft=ft, y_onehot=y)            # CPU tensor: no fallback
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_multi_level_flow_with_split2d_golden(golden_dir, tag):
+    """FlowUpsamplerNet with three levels and Split2d layers between them (FlowUpsamplerNet.py:149-167,243-269,292-311; channel
+    counts 12, 24, 96 with one split / 12, 24, 48 with two) against the reference's outputs (make_golden_general.py): the
+    epses list of the encode, the decode from it, the plain encode; the caller's list survives the decode; a decode without
+    epses draws them.  These configurations run layer by layer on the library's generic kernels."""
+    from interflow_amd.flow_modules import FlowUpsamplerNet
+    from tests.test_oracle_golden import GENERAL, general_case
+    from tests.golden.make_golden_general import general_opt, K
+    g = np.load(os.path.join(golden_dir, "general_seed5.npz"))
+    sd_np, x, feats = general_case(tag)
+    assert str(g[f"{tag}.digest"]) == synth.state_digest(sd_np)
+    fu = FlowUpsamplerNet((160, 160, 3), 64, K, flow_coupling='CondAffineSeparatedAndCond', LU_decomposed=True,
+                          opt=general_opt(tag == "b"))
+    fu.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+    fu.eval().to(dev())
+    assert fu._general and fu.C == (48 if tag == "b" else 96)
+    B, H = GENERAL["B"], GENERAL["H"]
+    x, feats, y = t(x).to(dev()), {k: t(v).to(dev()) for k, v in feats.items()}, t(g["y"])
+    epses, ld = fu(gt=x, rrdbResults=feats, epses=[], logdet=torch.zeros(B, device=dev()), reverse=False, y_onehot=y, test_input_size=H)
+    assert len(epses) == int(g[f"{tag}.n_eps"])
+    for i, e in enumerate(epses):
+        rel_close(e, g[f"{tag}.eps{i}"], what=f"eps {i}")
+    rel_close(ld, g[f"{tag}.ld"], what="logdet")
+    want = [t(g[f"{tag}.eps{i}"]).to(dev()) for i in range(len(epses))]
+    xr, ldr = fu(z=None, rrdbResults=feats, epses=want, logdet=t(g[f"{tag}.ld"]).to(dev()), reverse=True, y_onehot=y, test_input_size=H)
+    assert len(want) == len(epses)
+    rel_close(xr, g[f"{tag}.xr"], what="x")
+    assert float((ldr.cpu() - t(g[f"{tag}.ldr"])).abs().max()) <= RTOL * float(np.abs(g[f"{tag}.ld"]).max())   # sums to ~0
+    rel_close(xr, x.cpu().numpy(), what="round trip")
+    z, ld2 = fu(gt=x, rrdbResults=feats, logdet=torch.zeros(B, device=dev()), reverse=False, y_onehot=y, test_input_size=H)
+    rel_close(z, g[f"{tag}.z"], what="z"); rel_close(ld2, g[f"{tag}.ld2"], what="logdet (no list)")
+    xs, _ = fu(z=z, rrdbResults=feats, reverse=True, y_onehot=y, test_input_size=H, eps_std=0.5)     # eps drawn (Split.py:92-103)
+    assert xs.shape == x.shape and bool(torch.isfinite(xs).all())
+    with pytest.raises(KeyError):                                       # FlowUpsamplerNet.py:279-280: L=3 needs fea_up0
+        fu(z=z, rrdbResults={k: v for k, v in feats.items() if k != "fea_up0"}, reverse=True, y_onehot=y, test_input_size=H)
+    with pytest.raises(hip.InterflowHipError):                          # CPU tensor: no fallback
+        fu(gt=x.cpu(), rrdbResults=feats, reverse=False, y_onehot=y, test_input_size=H)
+
+
 # ----------------------------------------------------------------------------- whole stack
 def test_stack32_golden(golden_dir, sd_np, model):
     g = load(golden_dir, "stack32_seed0.npz", sd_np)

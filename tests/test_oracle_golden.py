@@ -240,3 +240,40 @@ def test_loss_with_class_zero_assigns_like_the_reference(sd_np):
     _, nll, _, _ = O.calculate_loss(z, ld, 12, label, [0, 4], means, covs)
     want0 = -(ld[0] + O.gaussian_logp(None, None, z[:1])[0]) / (np.log(2.) * 12)
     assert abs(float(nll[0] - want0)) < 1e-4 * abs(float(want0))
+
+
+GENERAL = dict(seed=5, L=3, K=2, extra=1, B=3, H=32, W=48)      # tests/golden/make_golden_general.py
+
+
+def general_case(tag):
+    """Weights and inputs of the multi-level fixture (synthesised here exactly as the generating script did)."""
+    c = GENERAL
+    sd_np = synth.synth_flow_state(c["seed"], L=c["L"], K=c["K"], extra=c["extra"], zeros_std=0.05,
+                                   split={"correct_splits": tag == "b"})
+    x = synth.synth_images(31, c["B"], c["H"], c["W"])
+    feats = synth.synth_features(32, c["B"], c["H"], c["W"], keys=("fea_up4", "fea_up2", "fea_up1", "fea_up0"))
+    return sd_np, x, feats
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_multi_level_flow_with_split2d(golden_dir, tag):
+    """FlowUpsamplerNet with L=3 and Split2d layers (one split / two splits) against the reference's outputs: the epses
+    list of the encode, the decode from it, the plain encode."""
+    g = _load(golden_dir, "general_seed5.npz")
+    sd_np, x, feats = general_case(tag)
+    assert str(g[f"{tag}.digest"]) == synth.state_digest(sd_np)
+    sd = O.to_torch(sd_np)
+    assert O.layer_kinds(sd, "").count("split") == (2 if tag == "b" else 1)
+    x, feats, y = t(x), {k: t(v) for k, v in feats.items()}, t(g["y"])
+    H, B = GENERAL["H"], GENERAL["B"]
+    epses, ld = O.flow_encode(x, feats, sd, "", torch.zeros(B), H, epses=[], y_onehot=y)
+    assert len(epses) == int(g[f"{tag}.n_eps"])
+    for i, e in enumerate(epses):
+        close(e, g[f"{tag}.eps{i}"], 1e-4, 1e-4)
+    close(ld, g[f"{tag}.ld"], 1e-5, 2e-2)
+    want = [t(g[f"{tag}.eps{i}"]) for i in range(len(epses))]
+    xr, ldr = O.flow_decode(None, feats, sd, "", t(g[f"{tag}.ld"]), H, n_levels=3, epses=want, y_onehot=y)
+    close(xr, g[f"{tag}.xr"], 1e-4, 1e-4); close(ldr, g[f"{tag}.ldr"], 1e-5, 2e-2)
+    assert len(want) == len(epses)                       # the caller's list is left alone (FlowUpsamplerNet.py:206)
+    z, ld2 = O.flow_encode(x, feats, sd, "", torch.zeros(B), H, y_onehot=y)
+    close(z, g[f"{tag}.z"], 1e-4, 1e-4); close(ld2, g[f"{tag}.ld2"], 1e-5, 2e-2)
