@@ -633,6 +633,19 @@ def test_generate_tiles_and_sharding(sd, model):
         merged += generate.assemble(u, rs, N, H, W, len(weights), dev())
     # flow kernels and encoder are batch-invariant, so ranks that batch differently still agree bit for bit
     assert seen == units and torch.equal(merged, full)
+    # hand-off to a host-side writer (generate.HostHandoff): the same bytes arrive at the sink, once per unit
+    for slots in (1, 3):
+        arrived = {}
+        u, rs = generate.generate(model, gd, lad, lbd, weights, tile=T, batch=3, sink=lambda unit, a: arrived.__setitem__(unit, a.copy()),
+                                  host_slots=slots)
+        assert rs is None and u == units and sorted(arrived) == sorted(units)     # batches go by tile shape, not in unit order
+        for unit, r in zip(units, res):
+            assert arrived[unit].dtype == np.uint8 and np.array_equal(arrived[unit], r.cpu().numpy())
+
+    def failing(unit, a):
+        raise OSError("disk full")
+    with pytest.raises(OSError):
+        generate.generate(model, gd, lad, lbd, weights, tile=T, batch=3, sink=failing)
     # whole-image mode (tile=None) is what the reference does
     u, rs = generate.generate(model, gd, lad, lbd, weights[:1], tile=None)
     with torch.no_grad():

@@ -67,3 +67,43 @@ def test_two_gloo_ranks_equal_one_process(tmp_path):
     assert sorted(a.files) == sorted(b.files) and len(a.files) == 3 * n
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_host_handoff_ring_order_backpressure_and_errors():
+    """generate.HostHandoff with host tensors (the GPU test covers the pinned / copy-stream leg): every unit reaches the sink
+    once, in order, with its own data; a slow sink with one slot throttles the producer instead of losing data; the sink's
+    exception surfaces in the producer."""
+    import threading
+    import time
+
+    import torch
+    from interflow_amd.generate import HostHandoff
+    got = []
+    with HostHandoff(lambda u, a: got.append((u, a.copy())), None, slots=2) as hh:
+        for b in range(5):
+            n = 1 + b % 3
+            hh.put([(b, j) for j in range(n)], torch.full((n, 2, 4, 4, 3), b, dtype=torch.uint8) + torch.arange(n, dtype=torch.uint8).view(n, 1, 1, 1, 1))
+    assert [u for u, _ in got] == [(b, j) for b in range(5) for j in range(1 + b % 3)]
+    assert all(a.shape == (2, 4, 4, 3) and (a == u[0] + u[1]).all() for u, a in got)
+    assert hh.batches == 5 and hh.bytes == sum((1 + b % 3) * 96 for b in range(5))
+    # one slot, slow sink: put() waits for the slot; nothing is overwritten while the sink still reads it
+    seen, inside = [], threading.Event()
+
+    def slow(u, a):
+        inside.set()
+        time.sleep(0.05)
+        seen.append(int(a[0, 0, 0, 0]))
+    t0 = time.time()
+    with HostHandoff(slow, None, slots=1) as hh:
+        for b in range(4):
+            hh.put([b], torch.full((1, 1, 2, 2, 3), b, dtype=torch.uint8))
+    assert seen == [0, 1, 2, 3] and time.time() - t0 >= 0.19
+    # sink failure
+    def bad(u, a):
+        raise OSError("disk full")
+    hh = HostHandoff(bad, None, slots=2)
+    hh.put([0], torch.zeros(1, 1, 2, 2, 3, dtype=torch.uint8))
+    with pytest.raises(OSError):
+        hh.close()
+    with pytest.raises(ValueError):
+        HostHandoff(bad, None, slots=0)

@@ -56,6 +56,25 @@ def main():
                        f"remainder), {len(weights)} weights per tile, uint8 NHWC outputs on the device",
            "n_gpus": world, "tiles": n_tiles, "seconds": dt, "tiles_per_s": n_tiles / dt,
            "outputs_per_s": n_tiles * len(weights) / dt, "images_per_s": N / dt}
+    # the same job with the results handed to a host-side writer (generate.HostHandoff: asynchronous copies into pinned
+    # buffers, a writer thread; the sink here checksums every array, standing in for the PNG encoder)
+    got = {"units": 0, "bytes": 0, "sum": 0}
+
+    def sink(u, a):
+        got["units"] += 1
+        got["bytes"] += a.nbytes
+        got["sum"] += int(a[:, ::16, ::16].sum())
+    generate.generate(model, gt, la, lb, weights[:2], tile=args.tile, batch=args.batch, rank=rank, world=world, sink=sink)   # pins the ring
+    generate.generate(model, gt, la, lb, weights, tile=args.tile, batch=min(args.batch, 8), rank=rank, world=world, sink=sink)
+    got.update(units=0, bytes=0, sum=0)
+    shard.barrier(dist, dev)
+    t0 = time.perf_counter()
+    generate.generate(model, gt, la, lb, weights, tile=args.tile, batch=args.batch, rank=rank, world=world, sink=sink)
+    shard.barrier(dist, dev)
+    dth = shard.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    out["host_handoff"] = {"seconds": dth, "tiles_per_s": n_tiles / dth, "images_per_s": N / dth,
+                           "rank0_units": got["units"], "rank0_host_bytes": got["bytes"],
+                           "note": "results delivered to a host-side sink through pinned buffers on a copy stream"}
     if rank == 0 and args.naive_tiles:
         T, nb = args.tile, args.naive_tiles
         cg = torch.stack([gt[0, :, 0:T, i * T:(i + 1) * T] for i in range(nb)]) if nb * T <= S else gt[:1, :, :T, :T].repeat(nb, 1, 1, 1)
