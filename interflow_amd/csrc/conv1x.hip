@@ -168,6 +168,15 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
     int grp, combo;
     {
         const int id = blockIdx.x;
+#ifdef IFL_EXP_PAIR2
+        // experiment: an XCD takes BOTH networks of one step for half of the tile groups; neighbouring workgroups of an XCD
+        // share a group's images through its L2 (half the image reads over the fabric, twice the weights per L2)
+        if ((ncombo & 7) == 0 && (ngroups & 1) == 0) {
+            const int x = id & 7, t = id >> 3, tl = t % ngroups;
+            grp = (tl >> 1) * 2 + (x >> 2);
+            combo = (t / ngroups) * 8 + (x & 3) * 2 + (tl & 1);
+        } else
+#endif
         if ((ncombo & 7) == 0) { const int t = id >> 3; grp = t % ngroups; combo = (t / ngroups) * 8 + (id & 7); }
         else { grp = id % ngroups; combo = id / ngroups; }
     }
