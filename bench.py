@@ -86,9 +86,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = shard.init_dist("nccl", dev)            # RCCL; only the barrier and the max-over-ranks clock use it
+    dev, backend = shard.rank_device()             # cuda:LOCAL_RANK, RCCL
+    torch.cuda.set_device(dev)
+    dist = shard.init_dist(backend, dev)            # RCCL; only the barrier and the max-over-ranks clock use it
 
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)
     model = InterpFlow(SCALES)

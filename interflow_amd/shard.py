@@ -21,6 +21,16 @@ def dist_env() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def rank_device():
+    """(device, backend) of this rank for the benchmarks: cuda:LOCAL_RANK and RCCL ("nccl").  IFL_REHEARSE_ONE_GPU=1 puts
+    every rank on cuda:0 with gloo for the collectives: a rehearsal of the multi-rank control flow (launch, barriers, the
+    clock, the gradient exchange) on a one-GPU box -- RCCL refuses two ranks on one device; its figures mean nothing."""
+    _, local_rank, _ = dist_env()
+    if os.environ.get("IFL_REHEARSE_ONE_GPU") == "1":
+        return torch.device("cuda", 0), "gloo"
+    return torch.device("cuda", local_rank), "nccl"
+
+
 def init_dist(backend: str, device=None):
     """Join the process group when WORLD_SIZE > 1 (MASTER_ADDR defaults to 127.0.0.1: one node).  Returns the
     torch.distributed module or None for a single process."""

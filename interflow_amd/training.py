@@ -18,12 +18,22 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
+import os
+
 import torch
 
 
 # the conditioning maps the shipped K=16, L=2 flow reads (FlowUpsamplerNet.py:66-73: level 1 -> 'fea_up2', level 2 -> 'fea_up1');
 # the training step asks the frozen encoder for these only (its full-resolution tail feeds nothing the flow uses)
 FLOW_FEATURES = ("fea_up1", "fea_up2")
+
+
+def _drain_for_gloo(dist, t):
+    """Rehearsal mode only (shard.rank_device: several ranks on ONE GPU, gloo because RCCL refuses that): gloo's all-reduce of a
+    device tensor never completes when it is issued while that device still has work queued (tools/exp_gloo_cuda.py
+    reproduces it without this library), so the device is drained first.  Nothing happens under RCCL or on CPU tensors."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(t.device)
 
 
 class GradientAllReducer:
@@ -77,7 +87,10 @@ class GradientAllReducer:
 
     def _launch(self, b):
         b["launched"] = True
+        if os.environ.get("IFL_DEBUG_REDUCER"):
+            print(f"[reducer rank {self.dist.get_rank() if self.dist else 0}] launch bucket {self.buckets.index(b)} n={b['flat'].numel()} pending={b['pending']}", flush=True)
         if self.dist is not None and self.world > 1:
+            _drain_for_gloo(self.dist, b["flat"])
             b["work"] = self.dist.all_reduce(b["flat"], async_op=True)
 
     def _on_grad(self, p):
@@ -113,12 +126,23 @@ def broadcast_parameters(model: torch.nn.Module, dist, src: int = 0):
     """Make every replica equal to rank `src` (parameters and buffers)."""
     if dist is None or dist.get_world_size() == 1:
         return
-    seen = set()
+    seen, groups = set(), {}
     for t in list(model.parameters()) + list(model.buffers()):
         if id(t) in seen:
             continue
         seen.add(id(t))
-        dist.broadcast(t.data, src)
+        groups.setdefault((t.dtype, t.device), []).append(t.data)
+    # one flat buffer and ONE collective per dtype (≈1 500 tensors, 125 MB: per-tensor broadcasts cost a launch and a
+    # rendezvous each -- minutes over gloo, milliseconds each over RCCL)
+    for ts in groups.values():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        _drain_for_gloo(dist, flat)
+        dist.broadcast(flat, src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
 
 
 def _uninitialised_actnorms(model):
@@ -154,6 +178,7 @@ def init_actnorm(model, gt, low_res, dist=None, lr_enc=None, src: int = 0):
     multi = dist is not None and dist.get_world_size() > 1
     if multi:                                   # every rank must take the same branch: the broadcast below is a collective
         flag = torch.tensor([float(n)], device=gt.device)
+        _drain_for_gloo(dist, flag)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         n = int(flag.item())
     if n == 0:
@@ -347,6 +372,7 @@ def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_
         flag = (~torch.isfinite(l)) | ((l > 30) if step > 100 else torch.zeros_like(l, dtype=torch.bool))   # train.py:113-126
         flag = flag.to(torch.float32).reshape(())
         if dist is not None and dist.get_world_size() > 1:
+            _drain_for_gloo(dist, flag)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # collective decision, on the device
         if reducer is not None:
             reducer.finish()
@@ -363,6 +389,7 @@ def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_
     bad = (terms[0] != terms[0] or abs(terms[0]) == float("inf")) or (step > 100 and terms[0] > 30)     # :113-126
     if dist is not None and dist.get_world_size() > 1:
         flag = torch.tensor([1.0 if bad else 0.0], device=device)
+        _drain_for_gloo(dist, flag)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         bad = bool(flag.item() > 0)
     if bad:
@@ -471,6 +498,7 @@ def _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, 
     bad = (not bool(torch.isfinite(loss))) or (step > 100 and float(loss.detach()) > 30)         # :113-126
     if dist is not None and dist.get_world_size() > 1:
         flag = torch.tensor([1.0 if bad else 0.0], device=gt.device)
+        _drain_for_gloo(dist, flag)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         bad = bool(flag.item() > 0)
     if bad:

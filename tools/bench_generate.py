@@ -33,9 +33,9 @@ def main():
     ap.add_argument("--naive-tiles", type=int, default=32)
     args = ap.parse_args()
     rank, local_rank, world = shard.dist_env()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = shard.init_dist("nccl", dev)
+    dev, backend = shard.rank_device()             # cuda:LOCAL_RANK, RCCL
+    torch.cuda.set_device(dev)
+    dist = shard.init_dist(backend, dev)
     model = InterpFlow([2, 4])
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_interpflow_state([2, 4], seed=0).items()})
     model.eval().to(dev)

@@ -35,10 +35,13 @@ def main():
     ap.add_argument("--late-check", action="store_true", help="train_step(late_check=True): no host read of the loss before the backward pass")
     ap.add_argument("--frozen-rrdb", action="store_true", help="do not train the conditioning encoder (no gradient wrt ft)")
     args = ap.parse_args()
+    if os.environ.get("IFL_WATCHDOG_S"):           # a stuck rank prints every thread's stack and exits (collective mismatches)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["IFL_WATCHDOG_S"]), exit=True)
     rank, local_rank, world = shard.dist_env()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = shard.init_dist("nccl", dev)
+    dev, backend = shard.rank_device()             # cuda:LOCAL_RANK, RCCL
+    torch.cuda.set_device(dev)
+    dist = shard.init_dist(backend, dev)
     model = InterpFlow([2, 4])
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_interpflow_state([2, 4], seed=0).items()})
     model.train().to(dev)
