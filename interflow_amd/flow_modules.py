@@ -487,8 +487,17 @@ class FlowUpsamplerNet(nn.Module):
             return True
         return any(p.requires_grad for p in self.layers.parameters())
 
+    def _actnorm_init_due(self):
+        """Training mode with ActNorms whose data-dependent initialisation is still due (FlowActNorms.py:29-43; flow.py:57-63):
+        the reference initialises them inside the first training-mode forward, with or without autograd; so does the
+        layer-by-layer evaluation, which this pass then takes (the fused driver packs finished parameters only)."""
+        if not self.training:
+            return False
+        from .training import _uninitialised_actnorms
+        return bool(_uninitialised_actnorms(self))
+
     def _run(self, src, rrdbResults, logdet, test_input_size, decode, epses=None, y_onehot=None, eps_std=None):
-        if self._general or self._needs_autograd(src, rrdbResults):
+        if self._general or self._needs_autograd(src, rrdbResults) or self._actnorm_init_due():
             from . import train_flow
             out, ld = train_flow.run(self, src, rrdbResults, logdet, test_input_size, decode, epses=epses, y_onehot=y_onehot,
                                      eps_std=eps_std)

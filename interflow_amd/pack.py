@@ -186,8 +186,8 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
     logs = prm[pfx + "actnorm.logs"].reshape(-1).astype(F32)
     if training and not np.any(bias != 0):
         raise NotImplementedError(
-            "data-dependent ActNorm initialisation (FlowActNorms.py:29-43) is not implemented in the HIP path; "
-            "load initialised parameters or call .eval()")
+            "the fused driver packs initialised ActNorm parameters only: FlowUpsamplerNet runs the data-dependent "
+            "initialisation (FlowActNorms.py:29-43) in its first training-mode pass; here, load initialised parameters or call .eval()")
     w, winv, sum_log_s = invconv_matrices(prm, pfx + "invconv.")
     put(hip.F_ANIC_FWD, np.concatenate([bias, np.exp(logs), w.reshape(-1)]))
     put(hip.F_ANIC_INV, np.concatenate([bias, np.exp(-logs), winv.reshape(-1)]))
@@ -199,7 +199,7 @@ def pack_step(prm, pfx, C, has_coupling, out, training=False):
                 (1, "affine.fFeatures.", hip.F_W1F, hip.F_AN1F, hip.F_W2F, hip.F_AN2F, hip.F_W3F, hip.F_B3F)):
             q = pfx + name
             if training and not np.any(prm[q + "0.actnorm.bias"] != 0):
-                raise NotImplementedError("data-dependent ActNorm initialisation is not implemented in the HIP path")
+                raise NotImplementedError("uninitialised ActNorm inside a coupling network: see FlowUpsamplerNet._actnorm_init_due")
             put(fw1, _pack_conv1(prm[q + "0.weight"].astype(F32), ch if net == 0 else 0, kz if net == 0 else 0))
             put(fan1, _pack_actnorm64(prm[q + "0.actnorm.bias"], prm[q + "0.actnorm.logs"]))
             put(fw2, _pack_conv2(prm[q + "2.weight"].astype(F32)))

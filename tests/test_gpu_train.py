@@ -412,6 +412,16 @@ def test_actnorm_init_against_reference_fixture(golden_dir):
             worst = max(worst, dl, db)
     print("ActNorm init vs reference: worst rel err over 328 tensors %.2e" % worst)
     assert worst < 2e-4
+    # without autograd (the reference initialises inside any training-mode forward): the same parameters, and the next pass
+    # runs on the fused driver with them
+    model3 = fresh()
+    with torch.no_grad():
+        z3, ld3 = model3.flow_upsampler(gt=x, rrdbResults=feats, logdet=torch.zeros(B, device=dev()), reverse=False, test_input_size=H)
+        got3 = model3.flow_upsampler.state_dict()
+        assert all(torch.equal(got3[k[2:]], got[k[2:]]) for k in g.files if k.startswith("p_"))
+        assert rel(z3, torch.from_numpy(g["z"])) < 1e-4 and not model3.flow_upsampler._actnorm_init_due()
+        z4, ld4 = model3.flow_upsampler(gt=x, rrdbResults=feats, logdet=torch.zeros(B, device=dev()), reverse=False, test_input_size=H)
+        assert rel(z4, z3.cpu()) < 1e-4 and rel(ld4, ld3.cpu()) < 1e-4
     # the explicit helper of the training loop does the same and reports what it initialised
     model2 = fresh()
     n = training.init_actnorm(model2, x, x, None, lr_enc=feats)
