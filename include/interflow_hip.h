@@ -167,6 +167,13 @@ int ifl_set_conv1_algo(int algo);
  * forms lay out fFeatures' log-det partial sums differently).                                                            */
 int ifl_set_conv3_algo(int algo);
 
+/* Encode chain: a conditional step's ActNorm2d + InvertibleConv1x1 (FlowActNorms.py:87-92, Permutations.py:114-118) applied
+ * inside the kernel that finishes fAffine's first two layers (two launches per step instead of three, the mapped latent written
+ * to a second buffer of the workspace; same arithmetic, bit-identical results; no counterpart in the reference).  1 = on
+ * (default), 0 = separate kernels.  Environment IFL_FUSE_ANIC=0/1 sets the default at load.  Any other value only queries.
+ * Returns the previous setting.                                                                                          */
+int ifl_set_chain_fusion(int on);
+
 /* ---- stand-alone operators on NCHW tensors ---- */
 /* squeeze2d / unsqueeze2d, flow.py:163-193 (pure index permutation, bit-exact). */
 int ifl_squeeze2d(const float* in, float* out, int B, int C, int H, int W, int factor, void* stream);

@@ -162,6 +162,7 @@ int ifl_ws_layout(void* base, int B, int H, int W, IflWs* out)
         lv.ft = take(ring * IFL_FT);
         lv.vg = take(ifl_vg_floats(B, lv.H, lv.W));
         lv.z = take(ring * lv.C);
+        lv.z2 = take(ring * lv.C);
         lv.h2_step = ring * IFL_H2;
         lv.h2 = take(lv.h2_step * IFL_MAX_COND);
         lv.ha = take(ring * IFL_HID);
@@ -264,16 +265,39 @@ static int chain_conv3(const ifl_layer& L, const float* params, const IflWs& w, 
 // ---- one FlowStep on a level's ringed buffers -------------------------------------------------------------------
 // `slab` is the step's index among the level's conditional steps: its h2 slab holds the conditioning-only part of the first
 // conv (conv1_ft) and its sf slab fFeatures' shift / scale (conv3f); both are written by phase 1.
+// IFL_FUSE_ANIC (default 1): in the encode chain a conditional step's ActNorm + 1x1 conv runs inside its conv1_finish kernel
+// (ifl_k_conv1_finish_pre: two launches per step instead of three); 0 = the separate kernels
+static int& fuse_anic()
+{
+    static int v = env_int0("IFL_FUSE_ANIC", 1) != 0;
+    return v;
+}
+
+// swap_z (may be null): the caller lets this step put the mapped latent into lv.z2; *swap_z = 1 tells it that lv.z and lv.z2
+// have changed roles (the running latent is now in what was lv.z2)
 static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
-                       int& slots, double& constant, float eps, int bf16, hipStream_t st)
+                       int& slots, double& constant, float eps, int bf16, hipStream_t st, int* swap_z = nullptr)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
     int rc;
-    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, nullptr, st); }
-    if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant += (double)L.sum_logs * px + (double)L.sum_log_s * px;
+    if (L.kind == 2 && swap_z && !bf16 && fuse_anic()) {
+        const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
+        const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
+        { ProfScope ps(IFL_K_CONV1_FINISH, st);
+          rc = ifl_k_conv1_finish_pre(lv.z, lv.z2, prm + off.anic_fwd, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st); }
+        if (rc) return rc;
+        IflLevelWs lz = lv;
+        lz.z = lv.z2; lz.z2 = lv.z;
+        { ProfScope ps(IFL_K_CONV3_ENC, st);
+          rc = chain_conv3(L, params, w, lz, sf, slots, 0, eps, bf16, st); }
+        *swap_z = 1;
+        return rc;
+    }
+    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_fwd, w.B, L.C, lv.H, lv.W, 0, nullptr, st); }
+    if (rc) return rc;
     if (L.kind == 2) {
         const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
         const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
@@ -453,7 +477,7 @@ IflWs ws_slice(const IflWs& w, int b0, int nb)
     for (int l = 0; l < IFL_MAX_LEVELS; ++l) {
         IflLevelWs& lv = s.lv[l];
         int64_t ring = (int64_t)b0 * (lv.H + 2) * (lv.W + 2);
-        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.h2 += ring * IFL_H2; lv.ha += ring * IFL_HID;     // h2_step, sf_step stay the full-batch slab strides
+        lv.ft += ring * IFL_FT; lv.z += ring * lv.C; lv.z2 += ring * lv.C; lv.h2 += ring * IFL_H2; lv.ha += ring * IFL_HID;     // h2_step, sf_step stay the full-batch slab strides
         lv.sf += ring * 2 * lv.C;
     }
     s.ldpart += (int64_t)b0 * w.ld_slots;
@@ -517,20 +541,23 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
     };
     if (!decode) {
         int lvl = -1;
+        IflWs wm = w;                             // lv[].z / lv[].z2 change roles after every step that maps z out of place
         for (int i = 0; i < n_layers; ++i) {
             const ifl_layer& L = layers[i];
             if (L.kind == 0) {
                 ++lvl;
-                if (lvl == 0) rc = ifl_k_squeeze_in(src, w.lv[0].z, B, 3, H, W, st);
-                else rc = ifl_k_squeeze_ring(w.lv[lvl - 1].z, w.lv[lvl].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
+                if (lvl == 0) rc = ifl_k_squeeze_in(src, wm.lv[0].z, B, 3, H, W, st);
+                else rc = ifl_k_squeeze_ring(wm.lv[lvl - 1].z, wm.lv[lvl].z, B, wm.lv[lvl - 1].C, wm.lv[lvl - 1].H, wm.lv[lvl - 1].W, st);
             } else {
                 const int slab = plan.slab_of_layer[i];
                 if (slab >= 0 && (rc = wait_slab(lvl, slab))) return rc;
-                rc = step_encode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, (bf16 >> 1) & 1, st);
+                int swapped = 0;
+                rc = step_encode(L, params, wm, wm.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, (bf16 >> 1) & 1, st, &swapped);
+                if (swapped) { float* tz = wm.lv[lvl].z; wm.lv[lvl].z = wm.lv[lvl].z2; wm.lv[lvl].z2 = tz; }
             }
             if (rc) return rc;
         }
-        const IflLevelWs& last = w.lv[lvl];
+        const IflLevelWs& last = wm.lv[lvl];
         if ((rc = ifl_k_ring_to_nchw(last.z, dst, B, last.C, last.H, last.W, st))) return rc;
     } else {
         int lvl = IFL_MAX_LEVELS - 1;
@@ -619,6 +646,13 @@ extern "C" int ifl_set_conv1_algo(int algo)
 {
     int prev = conv1_algo();
     if (algo >= 0 && algo <= 2) conv1_algo() = algo;
+    return prev;
+}
+
+extern "C" int ifl_set_chain_fusion(int on)
+{
+    int prev = fuse_anic();
+    if (on == 0 || on == 1) fuse_anic() = on;
     return prev;
 }
 

@@ -629,13 +629,22 @@ void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
 // ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
 // 4 waves x 32 pixels; each wave owns all 64 channels of its pixels.  K = 9 taps x KZ channels (C/2 padded to a multiple
 // of 8 with zero weights).
-template <int KZ, bool BF16>
+// PRE = 1 (encode chain): the step's ActNorm2d + InvertibleConv1x1 (pointwise.hip: anic, y = W ((x + b) .* exp(logs)),
+// FlowActNorms.py:87-92, Permutations.py:114-118) is applied here, on the way into LDS, instead of by a kernel of its own
+// before this one: every patch pixel's z is read from `zP` (the running latent BEFORE the map), mapped, its first KZ channels
+// staged for the taps (pixels outside the plane stay zero: the convolution pads the MAPPED z1), and the tile's own pixels are
+// written, all C channels, to `zoutP` -- a second buffer, because the neighbouring workgroups still read the unmapped halo.
+// One launch and one z round trip less per conditional step of the sequential chain.  C = 12: a thread per patch pixel, W as
+// LDS broadcasts; C = 48: v_mfma_f32_16x16x4_f32 with anic48_mfma_kernel's operand layout (a wave takes 64 patch pixels).
+template <int KZ, bool BF16, int PRE = 0>
 __global__ __launch_bounds__(256, 2)
 void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__ h2P, float* __restrict__ haP,
-                         const float* __restrict__ prm, IflStepOff off, IflGeom g, int C)
+                         const float* __restrict__ prm, IflStepOff off, IflGeom g, int C,
+                         float* __restrict__ zoutP = nullptr, const float* __restrict__ anicP = nullptr)
 {
     constexpr int NT = 1;
     __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * (KZ + 4)];     // KZ = 8: 14.6 KB, KZ = 24: 34 KB
+    __shared__ __attribute__((aligned(16))) float sw[PRE == 1 && KZ == 8 ? 12 * 12 + 24 : 4];
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;
     const int b = blockIdx.y;
@@ -652,11 +661,105 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
     lane_pixels<NT>(t, g, b, wave * 32, j, h, CSZ, a0, opix);
 
     const float* z_b = zP + (int64_t)b * (g.H + 2) * W2 * C;
-    for (int idx = tid; idx < t.PP * nq; idx += 256) {
-        int p = idx / nq, q = idx - p * nq;
-        int r = p / t.PW, c = p - r * t.PW;
-        f32x4 v = *(const f32x4*)(z_b + (int64_t)((t.y_first + 1 + r) * W2 + t.x0 + c) * C + q * 4);
-        *(f32x4*)&lds[p * CSZ + q * 4] = v;
+    if constexpr (PRE == 0) {
+        for (int idx = tid; idx < t.PP * nq; idx += 256) {
+            int p = idx / nq, q = idx - p * nq;
+            int r = p / t.PW, c = p - r * t.PW;
+            f32x4 v = *(const f32x4*)(z_b + (int64_t)((t.y_first + 1 + r) * W2 + t.x0 + c) * C + q * 4);
+            *(f32x4*)&lds[p * CSZ + q * 4] = v;
+        }
+    } else {
+        float* zo_b = zoutP + (int64_t)b * (g.H + 2) * W2 * C;
+        const int e_end = t.s + g.tpx < t.npx ? t.s + g.tpx : t.npx;       // the tile's pixels: band indices [t.s, e_end)
+        // patch pixel p = (r, c): ring row t.y_first + 1 + r, ring column t.x0 + c; inside the plane when both are in 1..H / 1..W;
+        // one of this tile's own pixels when its band index (row * bwb + c - 1) falls into [t.s, e_end)
+        if constexpr (KZ == 8) {                 // C == 12
+            constexpr int CC = 12;
+            for (int i = tid; i < CC * CC + 2 * CC; i += 256) sw[i] = anicP[i];
+            __syncthreads();
+            for (int p = tid; p < t.PP; p += 256) {
+                const int r = p / t.PW, c = p - r * t.PW;
+                const int ry = t.y_first + 1 + r, rx = t.x0 + c;
+                f32x4 o[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                if (ry >= 1 && ry <= g.H && rx >= 1 && rx <= g.W) {
+                    const int64_t po = ((int64_t)ry * W2 + rx) * CC;
+                    float v[CC];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const f32x4 x = *(const f32x4*)(z_b + po + q * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float u = x[e] + sw[q * 4 + e]; v[q * 4 + e] = u * sw[CC + q * 4 + e]; }
+                    }
+#pragma unroll
+                    for (int co = 0; co < CC; ++co) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ci = 0; ci < CC; ci += 4) {
+                            const f32x4 w = *(const f32x4*)(sw + 2 * CC + co * CC + ci);
+                            acc = fmaf(w[0], v[ci], acc); acc = fmaf(w[1], v[ci + 1], acc);
+                            acc = fmaf(w[2], v[ci + 2], acc); acc = fmaf(w[3], v[ci + 3], acc);
+                        }
+                        o[co >> 2][co & 3] = acc;
+                    }
+                    const int bi = (ry - 1) * t.bwb + c - 1;
+                    if (c >= 1 && c <= t.bwb && bi >= t.s && bi < e_end) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) *(f32x4*)(zo_b + po + q * 4) = o[q];
+                    }
+                }
+                *(f32x4*)&lds[p * CSZ] = o[0];
+                *(f32x4*)&lds[p * CSZ + 4] = o[1];
+            }
+        } else {                                 // C == 48
+            constexpr int CC = 48;
+            const int n = lane & 15, gk = lane >> 4;
+            const float* wm = anicP + 2 * CC;
+            f32x4 a[3][3], bb[3], sc[3];
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                bb[tt] = *(const f32x4*)(anicP + 16 * tt + 4 * gk);
+                sc[tt] = *(const f32x4*)(anicP + CC + 16 * tt + 4 * gk);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) a[tt][jj] = *(const f32x4*)(wm + (16 * tt + n) * CC + 16 * jj + 4 * gk);
+            }
+            for (int base = wave * 64; base < t.PP; base += 256) {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    const int p = base + pt * 16 + n;
+                    const bool live = p < t.PP;
+                    const int pc = live ? p : 0;
+                    const int r = pc / t.PW, c = pc - r * t.PW;
+                    const int ry = t.y_first + 1 + r, rx = t.x0 + c;
+                    const bool inplane = live && ry >= 1 && ry <= g.H && rx >= 1 && rx <= g.W;
+                    const int64_t po = ((int64_t)ry * W2 + rx) * CC + 4 * gk;
+                    f32x4 v[3];
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        v[jj] = inplane ? *(const f32x4*)(z_b + po + 16 * jj) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        v[jj] = v[jj] + bb[jj]; v[jj] = v[jj] * sc[jj];
+                    }
+                    f32x4 acc[3];
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][jj][e], v[jj][e], acc[tt], 0, 0, 0);
+                    }
+                    if (!inplane) { acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; }
+                    const int bi = (ry - 1) * t.bwb + c - 1;
+                    if (inplane && c >= 1 && c <= t.bwb && bi >= t.s && bi < e_end) {
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) *(f32x4*)(zo_b + po + 16 * tt) = acc[tt];
+                    }
+                    if (live) {                  // channels 0..23 = z1: accumulator 0 (4 gk ..) and, for gk < 2, accumulator 1 (16 + 4 gk ..)
+                        *(f32x4*)&lds[p * CSZ + 4 * gk] = acc[0];
+                        if (gk < 2) *(f32x4*)&lds[p * CSZ + 16 + 4 * gk] = acc[1];
+                    }
+                }
+            }
+        }
     }
     // accumulators start from the stored conditioning-part sums
     f32x16 acc[2][NT];
@@ -742,6 +845,20 @@ int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, c
 #ifdef IFL_EXP_TIME
 extern "C" int ifl_dbg_read(void* host, size_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ifl_dbg), bytes); }
 #endif
+
+// conv1_finish with the step's ActNorm + 1x1 conv applied on the way in (encode chain, fp32): reads z_in, writes the mapped z
+// of every pixel to z_out (another buffer with a zero ring) and fAffine's finished hidden activations to ha
+int ifl_k_conv1_finish_pre(const float* z_in, float* z_out, const float* anic_fwd, const float* h2, float* ha, const float* prm,
+                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st)
+{
+    dim3 grid(g.ntiles, B), block(256);
+    if (z_in == z_out) { ifl_set_error("conv1_finish (fused ActNorm + 1x1): the mapped z needs a buffer of its own"); return IFL_EINVAL; }
+    if (C == 12) hipLaunchKernelGGL((conv1_finish_kernel<8, false, 1>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd);
+    else if (C == 48) hipLaunchKernelGGL((conv1_finish_kernel<24, false, 1>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd);
+    else { ifl_set_error("conv1_finish (fused ActNorm + 1x1): C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
+    IFL_LAUNCH_CHECK();
+    return 0;
+}
 
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, int bf16, hipStream_t st)

@@ -135,6 +135,8 @@ struct IflLevelWs {
     float* ft;                // [B][H+2][W+2][320]  zero ring
     float* vg;                // the same features in the Winograd F(4x4,3x3) domain (IflXGeom, conv1x.hip)
     float* z;                 // [B][H+2][W+2][C]    zero ring
+    float* z2;                // a second latent buffer of the same shape: the encode chain's fused ActNorm + 1x1 + conv1_finish
+                              //   kernel writes the mapped z here (its neighbours still read the unmapped halo), then the two swap roles
     float* h2;                // [IFL_MAX_COND][B][H+2][W+2][128]  zero ring; one slab per conditional step: [0:64] fAffine's
                               //   conditioning-only pre-activation sums, [64:128] fFeatures' finished hidden activations
     float* ha;                // [B][H+2][W+2][64]  zero ring; fAffine's finished hidden activations of the step in flight
@@ -221,6 +223,8 @@ int ifl_k_conv1_ft_wino(const float* ft, float* h2all, int64_t h2_step_stride, c
 int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipStream_t st);                    // ringed NHWC -> vg
 int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                          int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st, int raw_both = 0);
+int ifl_k_conv1_finish_pre(const float* z_in, float* z_out, const float* anic_fwd, const float* h2, float* ha, const float* prm,
+                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, int bf16, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (fAffine's conv, both couplings), 2 = decode (fAffine's conv and coupling)

@@ -111,6 +111,8 @@ def lib():
     L.ifl_set_conv1_algo.restype = c_int
     L.ifl_set_conv3_algo.argtypes = [c_int]
     L.ifl_set_conv3_algo.restype = c_int
+    L.ifl_set_chain_fusion.argtypes = [c_int]
+    L.ifl_set_chain_fusion.restype = c_int
     L.ifl_an_relu_blocks.argtypes = [c_int, c_int, c_int]
     L.ifl_an_relu_blocks.restype = c_int64
     L.ifl_an_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -148,7 +150,7 @@ EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_f
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
            "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
-           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo",
+           "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo", "ifl_set_chain_fusion",
            "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep",
            "ifl_adam_table", "ifl_wino4_untile", "ifl_rrdb_train_ws_bytes", "ifl_rrdb_train_ws_init", "ifl_rrdb_train_fwd", "ifl_rrdb_train_bwd", "ifl_pack_table", "ifl_affine_px_blocks", "ifl_train_level_fwd", "ifl_train_level_bwd", "ifl_train_vg_floats",
            "ifl_train_bulk_conv1", "ifl_wino4_tiles", "ifl_wino4_kmajor", "ifl_wino4_dw", "ifl_conv2d_wgrad_batched", "ifl_conv2d_batched")
@@ -171,6 +173,12 @@ def set_conv1_algo(algo: int = -1) -> int:
 
 
 CONV3_DIRECT, CONV3_WINOGRAD = 0, 1
+
+
+def set_chain_fusion(on: int = -1) -> int:
+    """Encode chain with a conditional step's ActNorm + 1x1 conv inside its conv1_finish kernel (ifl_set_chain_fusion): 1
+    (default) or 0; any other value only queries.  Returns the previous setting.  Results are bit-identical either way."""
+    return int(lib().ifl_set_chain_fusion(on))
 
 
 def set_conv3_algo(algo: int = -1) -> int:

@@ -236,6 +236,27 @@ def test_full160_golden(golden_dir, sd_np, model):
     print(f"full160 rel errs: z {e1:.2e} logdet {e2:.2e} x {e3:.2e} logdet_rev {e4:.2e}")
 
 
+def test_chain_fusion_gives_the_same_bits(model):
+    """The encode chain with a step's ActNorm + 1x1 conv inside conv1_finish (two launches per step, the mapped latent in the
+    workspace's second z buffer) against the three-kernel chain: same arithmetic, so z and logdet are bit-identical -- at
+    the patch size, on odd planes (20x36: tiles and bands with remainders) and with an odd batch (sample groups 2 + 1)."""
+    assert hip.set_chain_fusion(-1) == 1
+    for B, H, W in ((3, 160, 160), (2, 20, 36), (1, 8, 12)):
+        x = t(synth.synth_images(71, B, H, W)).to(dev())
+        feats = {k: t(v).to(dev()) for k, v in synth.synth_features(72, B, H, W).items()}
+        fu = model.flow_upsampler
+        z1, ld1 = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+        z1b, _ = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)              # the second buffer now holds stale data
+        prev = hip.set_chain_fusion(0)
+        try:
+            z0, ld0 = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+        finally:
+            hip.set_chain_fusion(prev)
+        assert torch.equal(z1, z0) and torch.equal(ld1, ld0) and torch.equal(z1b, z0), (B, H, W, float((z1 - z0).abs().max()))
+        xr, _ = fu(z=z1, rrdbResults=feats, logdet=0., reverse=True)
+        rel_close(xr, x.cpu().numpy(), what="round trip")
+
+
 @pytest.mark.parametrize("algo", [hip.CONV1_DIRECT, hip.CONV1_WINOGRAD, hip.CONV1_WINOGRAD4])
 def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
     """Both forms of the bulk convolution (direct implicit GEMM, Winograd F(2x2,3x3)) meet the tolerance against the
