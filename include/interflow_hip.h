@@ -169,9 +169,9 @@ int ifl_set_conv3_algo(int algo);
 
 /* Encode chain: a conditional step's ActNorm2d + InvertibleConv1x1 (FlowActNorms.py:87-92, Permutations.py:114-118) applied
  * inside the kernel that finishes fAffine's first two layers (two launches per step instead of three, the mapped latent written
- * to a second buffer of the workspace; same arithmetic, bit-identical results; no counterpart in the reference).  1 = on
- * (default), 0 = separate kernels.  Environment IFL_FUSE_ANIC=0/1 sets the default at load.  Any other value only queries.
- * Returns the previous setting.                                                                                          */
+ * to a second buffer of the workspace; same arithmetic, bit-identical results; no counterpart in the reference).  Bit mask:
+ * bit 0 = steps with C = 12, bit 1 = steps with C = 48; default 2, 0 = separate kernels everywhere.  Environment
+ * IFL_FUSE_ANIC=0..3 sets the default at load.  Any other value only queries.  Returns the previous setting.            */
 int ifl_set_chain_fusion(int on);
 
 /* ---- stand-alone operators on NCHW tensors ---- */

@@ -644,7 +644,6 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
 {
     constexpr int NT = 1;
     __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * (KZ + 4)];     // KZ = 8: 14.6 KB, KZ = 24: 34 KB
-    __shared__ __attribute__((aligned(16))) float sw[PRE == 1 && KZ == 8 ? 12 * 12 + 24 : 4];
     const IflTile t = ifl_tile(g, blockIdx.x);
     if (!t.active) return;
     const int b = blockIdx.y;
@@ -675,8 +674,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
         // one of this tile's own pixels when its band index (row * bwb + c - 1) falls into [t.s, e_end)
         if constexpr (KZ == 8) {                 // C == 12
             constexpr int CC = 12;
-            for (int i = tid; i < CC * CC + 2 * CC; i += 256) sw[i] = anicP[i];
-            __syncthreads();
+            const float* sw = anicP;              // wave-uniform addresses: the map's 168 parameters come through the scalar cache
             for (int p = tid; p < t.PP; p += 256) {
                 const int r = p / t.PW, c = p - r * t.PW;
                 const int ry = t.y_first + 1 + r, rx = t.x0 + c;
@@ -776,6 +774,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
             }
     }
     __syncthreads();
+    if constexpr (PRE != 0) __builtin_amdgcn_sched_barrier(0);      // the tap loop's hoisted weight loads stay behind the map (registers)
     const float* wz = prm + off.w1[0] + (int64_t)NCC * (9 * 4 * 2 * 256) + lane * 4;
     constexpr int nkq = KZ / 8;               // compile-time, so the whole tap loop unrolls and its weight loads are hoisted
 #pragma unroll

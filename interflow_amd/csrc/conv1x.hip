@@ -161,23 +161,22 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
 {
     __shared__ __attribute__((aligned(16))) float lds[XLDS];              // V[0], V[1]; the epilogue's exchange slots
     // Workgroup -> (network, step, tile group).  A workgroup streams its network's whole transformed filter bank (2.95 MB per
-    // step) and every workgroup of a (network, step) pair streams the same one, so the pairs are dealt to the 8 XCDs
-    // (linear workgroup id % 8): each XCD works through all tile groups of ONE pair at a time and keeps that pair's
-    // weights in its 4 MB L2, instead of several pairs evicting each other.  The XCDs walk the tile groups in step, so a
-    // group's images are fetched from HBM once and served to the other XCDs by the Infinity Cache.
+    // step) and every workgroup of a (network, step) pair streams the same one; consecutive workgroup ids go to consecutive
+    // XCDs (id % 8).  With a multiple of 8 pairs and an even number of tile groups, an XCD takes BOTH networks of one step for
+    // half of the tile groups: the two workgroups of a tile group are neighbours on the XCD and share the group's images
+    // through its L2 (one fetch over the fabric instead of two: FETCH_SIZE per level-1 launch 3.3 GB against 5.0 GB with one
+    // pair per XCD, profiles/r02_notes.md), while the two filter banks (5.9 MB), walked in step by the XCD's workgroups, still
+    // stream through its 4 MB L2 once per round.  The XCDs walk the tile groups in step, so a group's images come from HBM
+    // once and the Infinity Cache serves the other XCDs.  Otherwise: one pair per XCD, or plain raster.
     int grp, combo;
     {
         const int id = blockIdx.x;
-#ifdef IFL_EXP_PAIR2
-        // experiment: an XCD takes BOTH networks of one step for half of the tile groups; neighbouring workgroups of an XCD
-        // share a group's images through its L2 (half the image reads over the fabric, twice the weights per L2)
         if ((ncombo & 7) == 0 && (ngroups & 1) == 0) {
             const int x = id & 7, t = id >> 3, tl = t % ngroups;
             grp = (tl >> 1) * 2 + (x >> 2);
             combo = (t / ngroups) * 8 + (x & 3) * 2 + (tl & 1);
-        } else
-#endif
-        if ((ncombo & 7) == 0) { const int t = id >> 3; grp = t % ngroups; combo = (t / ngroups) * 8 + (id & 7); }
+        }
+        else if ((ncombo & 7) == 0) { const int t = id >> 3; grp = t % ngroups; combo = (t / ngroups) * 8 + (id & 7); }
         else { grp = id % ngroups; combo = id / ngroups; }
     }
     const int step = combo >> 1, net = combo & 1;

@@ -176,8 +176,9 @@ CONV3_DIRECT, CONV3_WINOGRAD = 0, 1
 
 
 def set_chain_fusion(on: int = -1) -> int:
-    """Encode chain with a conditional step's ActNorm + 1x1 conv inside its conv1_finish kernel (ifl_set_chain_fusion): 1
-    (default) or 0; any other value only queries.  Returns the previous setting.  Results are bit-identical either way."""
+    """Encode chain with a conditional step's ActNorm + 1x1 conv inside its conv1_finish kernel (ifl_set_chain_fusion): bit
+    mask, 1 = steps with C = 12, 2 = steps with C = 48 (default 2), 0 = off; any other value only queries.  Returns the previous
+    setting.  Results are bit-identical whatever the setting."""
     return int(lib().ifl_set_chain_fusion(on))
 
 
