@@ -170,7 +170,8 @@ int ifl_set_conv3_algo(int algo);
 /* Encode chain: a conditional step's ActNorm2d + InvertibleConv1x1 (FlowActNorms.py:87-92, Permutations.py:114-118) applied
  * inside the kernel that finishes fAffine's first two layers (two launches per step instead of three, the mapped latent written
  * to a second buffer of the workspace; same arithmetic, bit-identical results; no counterpart in the reference).  Bit mask:
- * bit 0 = steps with C = 12, bit 1 = steps with C = 48; default 2, 0 = separate kernels everywhere.  Environment
+ * bit 0 = steps with C = 12 (encode only), bit 1 = steps with C = 48 (encode, and decode: the previous step's inverse pair plus
+ * this step's z = (z + shiftFt) * scaleFt, FlowAffineCouplingsAblation.py:170-175); default 2, 0 = separate kernels everywhere.  Environment
  * IFL_FUSE_ANIC=0..3 sets the default at load.  Any other value only queries.  Returns the previous setting.            */
 int ifl_set_chain_fusion(int on);
 

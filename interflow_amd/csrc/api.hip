@@ -313,27 +313,46 @@ static int step_encode(const ifl_layer& L, const float* params, const IflWs& w, 
 
 // fapply_done: the previous kernel of the chain already applied this step's z = (z + shiftFt) * scaleFt; sf_next: apply the
 // next step's (the one the chain runs after this one) in this step's last kernel.
+// pend_inv (may be null; chain fusion, C = 48): in: the inverse ActNorm + 1x1 block of the step the chain ran before this one,
+// whose map is still due -- it is applied, with this step's fapply, inside this step's conv1_finish (the mapped latent goes to
+// lv.z2, *swap_z = 1); out (may_defer: the chain's next layer is a conditional step too): this step's own block, left to the
+// next step instead of a kernel of its own.
 static int step_decode(const ifl_layer& L, const float* params, const IflWs& w, const IflLevelWs& lv, int slab,
                        int& slots, double& constant, float eps, int bf16, hipStream_t st, bool fapply_done = false,
-                       const float* sf_next = nullptr)
+                       const float* sf_next = nullptr, const float** pend_inv = nullptr, bool may_defer = false,
+                       int* swap_z = nullptr)
 {
     IflStepOff off = ifl_step_off(L.C, L.kind == 2);
     const float* prm = params + L.param_off;
     int rc;
+    IflLevelWs lz = lv;
     if (L.kind == 2) {
         const float* h2 = lv.h2 + (int64_t)slab * lv.h2_step;
         const float* sf = lv.sf + (int64_t)slab * lv.sf_step;
-        if (!fapply_done) {
-            ProfScope ps(IFL_K_CONV3_DEC, st);
-            if ((rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st))) return rc;
+        if (pend_inv && *pend_inv) {
+            { ProfScope ps(IFL_K_CONV1_FINISH, st);
+              rc = ifl_k_conv1_finish_pre(lv.z, lv.z2, *pend_inv, h2, lv.ha, prm, off, lv.geom, w.B, L.C, st, sf); }
+            if (rc) return rc;
+            lz.z = lv.z2; lz.z2 = lv.z;
+            *swap_z = 1;
+            *pend_inv = nullptr;
+        } else {
+            if (!fapply_done) {
+                ProfScope ps(IFL_K_CONV3_DEC, st);
+                if ((rc = ifl_k_fapply(sf, lv.z, w.B, L.C, lv.H, lv.W, st))) return rc;
+            }
+            { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, bf16, st); }
+            if (rc) return rc;
         }
-        { ProfScope ps(IFL_K_CONV1_FINISH, st); rc = ifl_k_conv1_finish(lv.z, h2, lv.ha, prm, off, lv.geom, w.B, L.C, bf16, st); }
-        if (rc) return rc;
         { ProfScope ps(IFL_K_CONV3_DEC, st);
-          rc = chain_conv3(L, params, w, lv, sf, slots, 2, eps, bf16, st); }
+          rc = chain_conv3(L, params, w, lz, sf, slots, 2, eps, bf16, st); }
         if (rc) return rc;
     }
-    { ProfScope ps(IFL_K_ANIC, st); rc = ifl_k_anic(lv.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, sf_next, st); }
+    if (pend_inv && may_defer && L.kind == 2) *pend_inv = prm + off.anic_inv;
+    else {
+        ProfScope ps(IFL_K_ANIC, st);
+        rc = ifl_k_anic(lz.z, prm + off.anic_inv, w.B, L.C, lv.H, lv.W, 1, sf_next, st);
+    }
     if (rc) return rc;
     double px = (double)lv.H * lv.W;
     constant -= (double)L.sum_logs * px + (double)L.sum_log_s * px;
@@ -562,14 +581,16 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
         if ((rc = ifl_k_ring_to_nchw(last.z, dst, B, last.C, last.H, last.W, st))) return rc;
     } else {
         int lvl = IFL_MAX_LEVELS - 1;
-        const IflLevelWs& last = w.lv[lvl];
+        IflWs wm = w;                             // lv[].z / lv[].z2 change roles after every step that maps z out of place
+        const IflLevelWs& last = wm.lv[lvl];
         if ((rc = ifl_k_nchw_to_ring(src, last.z, B, last.C, last.H, last.W, st))) return rc;
         bool fapply_done = false;
+        const float* pend_inv = nullptr;          // a deferred inverse ActNorm + 1x1 block (chain fusion)
         for (int i = n_layers - 1; i >= 0; --i) {
             const ifl_layer& L = layers[i];
             if (L.kind == 0) {
-                if (lvl == 0) rc = ifl_k_unsqueeze_out(w.lv[0].z, dst, B, 3, H, W, st);
-                else rc = ifl_k_unsqueeze_ring(w.lv[lvl].z, w.lv[lvl - 1].z, B, w.lv[lvl - 1].C, w.lv[lvl - 1].H, w.lv[lvl - 1].W, st);
+                if (lvl == 0) rc = ifl_k_unsqueeze_out(wm.lv[0].z, dst, B, 3, H, W, st);
+                else rc = ifl_k_unsqueeze_ring(wm.lv[lvl].z, wm.lv[lvl - 1].z, B, wm.lv[lvl - 1].C, wm.lv[lvl - 1].H, wm.lv[lvl - 1].W, st);
                 --lvl;
             } else {
                 const int slab = plan.slab_of_layer[i];
@@ -580,9 +601,14 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
                 if (i > 0 && layers[i - 1].kind == 2) {
                     const int nslab = plan.slab_of_layer[i - 1];
                     if ((rc = wait_slab(lvl, nslab))) return rc;
-                    sf_next = w.lv[lvl].sf + (int64_t)nslab * w.lv[lvl].sf_step;
+                    sf_next = wm.lv[lvl].sf + (int64_t)nslab * wm.lv[lvl].sf_step;
                 }
-                rc = step_decode(L, params, w, w.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, (bf16 >> 1) & 1, st, fapply_done, sf_next);
+                const int cbf = (bf16 >> 1) & 1;
+                const bool may_defer = sf_next != nullptr && !cbf && L.C == 48 && (fuse_anic() & 2);
+                int swapped = 0;
+                rc = step_decode(L, params, wm, wm.lv[lvl], slab < 0 ? 0 : slab, slots, constant, eps, cbf, st, fapply_done, sf_next,
+                                 &pend_inv, may_defer, &swapped);
+                if (swapped) { float* tz = wm.lv[lvl].z; wm.lv[lvl].z = wm.lv[lvl].z2; wm.lv[lvl].z2 = tz; }
                 fapply_done = sf_next != nullptr;
             }
             if (rc) return rc;

@@ -634,13 +634,16 @@ void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
 // before this one: every patch pixel's z is read from `zP` (the running latent BEFORE the map), mapped, its first KZ channels
 // staged for the taps (pixels outside the plane stay zero: the convolution pads the MAPPED z1), and the tile's own pixels are
 // written, all C channels, to `zoutP` -- a second buffer, because the neighbouring workgroups still read the unmapped halo.
+// PRE = 2 (decode chain, C = 48): the PREVIOUS step's inverse pair x = (Winv y) .* exp(-logs) - b followed by this step's
+// z = (z + shiftFt) * scaleFt from `sfP` -- what the previous step's last kernel (anic48 with sf_next) would have done.
 // One launch and one z round trip less per conditional step of the sequential chain.  C = 12: a thread per patch pixel, W as
 // LDS broadcasts; C = 48: v_mfma_f32_16x16x4_f32 with anic48_mfma_kernel's operand layout (a wave takes 64 patch pixels).
 template <int KZ, bool BF16, int PRE = 0>
 __global__ __launch_bounds__(256, 2)
 void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__ h2P, float* __restrict__ haP,
                          const float* __restrict__ prm, IflStepOff off, IflGeom g, int C,
-                         float* __restrict__ zoutP = nullptr, const float* __restrict__ anicP = nullptr)
+                         float* __restrict__ zoutP = nullptr, const float* __restrict__ anicP = nullptr,
+                         const float* __restrict__ sfP = nullptr)
 {
     constexpr int NT = 1;
     __shared__ __attribute__((aligned(16))) float lds[IFL_PP_MAX * (KZ + 4)];     // KZ = 8: 14.6 KB, KZ = 24: 34 KB
@@ -672,6 +675,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
         const int e_end = t.s + g.tpx < t.npx ? t.s + g.tpx : t.npx;       // the tile's pixels: band indices [t.s, e_end)
         // patch pixel p = (r, c): ring row t.y_first + 1 + r, ring column t.x0 + c; inside the plane when both are in 1..H / 1..W;
         // one of this tile's own pixels when its band index (row * bwb + c - 1) falls into [t.s, e_end)
+        static_assert(PRE == 1 || KZ == 24, "the inverse map is built for C = 48 only");
         if constexpr (KZ == 8) {                 // C == 12
             constexpr int CC = 12;
             const float* sw = anicP;              // wave-uniform addresses: the map's 168 parameters come through the scalar cache
@@ -734,7 +738,7 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj) {
                         v[jj] = inplane ? *(const f32x4*)(z_b + po + 16 * jj) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        v[jj] = v[jj] + bb[jj]; v[jj] = v[jj] * sc[jj];
+                        if constexpr (PRE == 1) { v[jj] = v[jj] + bb[jj]; v[jj] = v[jj] * sc[jj]; }
                     }
                     f32x4 acc[3];
 #pragma unroll
@@ -744,6 +748,22 @@ void conv1_finish_kernel(const float* __restrict__ zP, const float* __restrict__
                         for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][jj][e], v[jj][e], acc[tt], 0, 0, 0);
+                    }
+                    if constexpr (PRE == 2) {    // the inverse pair (Permutations.py:119-123, FlowActNorms.py:93-96), then this step's
+                                                 // z = (z + shiftFt) * scaleFt (FlowAffineCouplingsAblation.py:170-175), as anic48_mfma_kernel
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) { acc[tt] = acc[tt] * sc[tt]; acc[tt] = acc[tt] - bb[tt]; }
+                        if (inplane) {
+                            const float* sf = sfP + ((int64_t)(b * (g.H + 2) + ry) * W2 + rx) * (2 * CC) + 8 * gk;
+#pragma unroll
+                            for (int tt = 0; tt < 3; ++tt) {
+                                const f32x4 f0 = *(const f32x4*)(sf + 32 * tt), f1 = *(const f32x4*)(sf + 32 * tt + 4);
+                                acc[tt][0] = acc[tt][0] + f0[0]; acc[tt][0] = acc[tt][0] * f0[1];
+                                acc[tt][1] = acc[tt][1] + f0[2]; acc[tt][1] = acc[tt][1] * f0[3];
+                                acc[tt][2] = acc[tt][2] + f1[0]; acc[tt][2] = acc[tt][2] * f1[1];
+                                acc[tt][3] = acc[tt][3] + f1[2]; acc[tt][3] = acc[tt][3] * f1[3];
+                            }
+                        }
                     }
                     if (!inplane) { acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; }
                     const int bi = (ry - 1) * t.bwb + c - 1;
@@ -848,11 +868,15 @@ extern "C" int ifl_dbg_read(void* host, size_t bytes) { return (int)hipMemcpyFro
 // conv1_finish with the step's ActNorm + 1x1 conv applied on the way in (encode chain, fp32): reads z_in, writes the mapped z
 // of every pixel to z_out (another buffer with a zero ring) and fAffine's finished hidden activations to ha
 int ifl_k_conv1_finish_pre(const float* z_in, float* z_out, const float* anic_fwd, const float* h2, float* ha, const float* prm,
-                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st)
+                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st, const float* sf_inverse)
 {
     dim3 grid(g.ntiles, B), block(256);
     if (z_in == z_out) { ifl_set_error("conv1_finish (fused ActNorm + 1x1): the mapped z needs a buffer of its own"); return IFL_EINVAL; }
-    if (C == 12) hipLaunchKernelGGL((conv1_finish_kernel<8, false, 1>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd);
+    if (sf_inverse) {                         // decode: `anic_fwd` is the previous step's inverse block, sf_inverse this step's sf slab
+        if (C != 48) { ifl_set_error("conv1_finish (fused inverse ActNorm + 1x1): C=%d not supported (48)", C); return IFL_ENOTSUP; }
+        hipLaunchKernelGGL((conv1_finish_kernel<24, false, 2>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd, sf_inverse);
+    }
+    else if (C == 12) hipLaunchKernelGGL((conv1_finish_kernel<8, false, 1>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd);
     else if (C == 48) hipLaunchKernelGGL((conv1_finish_kernel<24, false, 1>), grid, block, 0, st, z_in, h2, ha, prm, off, g, C, z_out, anic_fwd);
     else { ifl_set_error("conv1_finish (fused ActNorm + 1x1): C=%d not supported (12 or 48)", C); return IFL_ENOTSUP; }
     IFL_LAUNCH_CHECK();

@@ -224,7 +224,7 @@ int ifl_k_wino4_input(const float* ft_ring, float* vg, int B, int H, int W, hipS
 int ifl_k_conv1_ft_wino4(const float* vg, float* h2all, int64_t h2_step_stride, const float* params, const IflStepList& steps,
                          int nsteps, const IflStepOff& off, int B, int H, int W, int level, hipStream_t st, int raw_both = 0);
 int ifl_k_conv1_finish_pre(const float* z_in, float* z_out, const float* anic_fwd, const float* h2, float* ha, const float* prm,
-                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st);
+                           const IflStepOff& off, const IflGeom& g, int B, int C, hipStream_t st, const float* sf_inverse = nullptr);
 int ifl_k_conv1_finish(const float* z, const float* h2, float* ha, const float* prm, const IflStepOff& off,
                        const IflGeom& g, int B, int C, int bf16, hipStream_t st);
 // conv3.hip:  mode: 0 = encode (fAffine's conv, both couplings), 2 = decode (fAffine's conv and coupling)

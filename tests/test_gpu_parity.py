@@ -237,8 +237,9 @@ def test_full160_golden(golden_dir, sd_np, model):
 
 
 def test_chain_fusion_gives_the_same_bits(model):
-    """The encode chain with a step's ActNorm + 1x1 conv inside conv1_finish (two launches per step, the mapped latent in the
-    workspace's second z buffer) against the three-kernel chain: same arithmetic, so z and logdet are bit-identical -- at
+    """The chains with a step's ActNorm + 1x1 conv (encode) / the previous step's inverse pair and this step's fapply (decode,
+    C = 48) inside conv1_finish (two launches per step, the mapped latent in the workspace's second z buffer) against the
+    three-kernel chains: same arithmetic, so z, x and the logdets are bit-identical -- at
     the patch size, on odd planes (20x36: tiles and bands with remainders) and with an odd batch (sample groups 2 + 1)."""
     default = hip.set_chain_fusion(-1)
     assert default == 2
@@ -250,13 +251,16 @@ def test_chain_fusion_gives_the_same_bits(model):
         try:
             for mask in (3, 3, 0, 1, 2):          # (the second pass with 3 finds stale data in the second buffer)
                 hip.set_chain_fusion(mask)
-                outs.setdefault(mask, []).append(fu(gt=x, rrdbResults=feats, logdet=0., reverse=False))
+                z_m, ld_m = fu(gt=x, rrdbResults=feats, logdet=0., reverse=False)
+                x_m, ldr_m = fu(z=z_m, rrdbResults=feats, logdet=0., reverse=True)      # (decode: the C = 48 bit folds the inverse pair too)
+                outs.setdefault(mask, []).append((z_m, ld_m, x_m, ldr_m))
         finally:
             hip.set_chain_fusion(default)
-        z0, ld0 = outs[0][0]
+        z0, ld0, x0, ldr0 = outs[0][0]
         for mask, runs in outs.items():
-            for z1, ld1 in runs:
+            for z1, ld1, x1, ldr1 in runs:
                 assert torch.equal(z1, z0) and torch.equal(ld1, ld0), (B, H, W, mask, float((z1 - z0).abs().max()))
+                assert torch.equal(x1, x0) and torch.equal(ldr1, ldr0), (B, H, W, mask, "decode", float((x1 - x0).abs().max()))
         z1 = z0
         xr, _ = fu(z=z1, rrdbResults=feats, logdet=0., reverse=True)
         rel_close(xr, x.cpu().numpy(), what="round trip")
