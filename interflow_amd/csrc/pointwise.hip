@@ -10,6 +10,7 @@
 //   lerp:  z = wa*za + wb*zb                               flow_model.py:186-200, train.py:88-92
 #include "ifl_common.h"
 
+#include <cstdint>
 #include <mutex>
 
 // Scratch of ifl_gaussian_logp_static (the entry point that allocates nothing): the per-block partial sums that
@@ -223,6 +224,78 @@ void logp_kernel(const float* __restrict__ z, const float* __restrict__ mean, co
     if (threadIdx.x == 0) scratch[(int64_t)b * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// C = 48 with a full covariance on the matrix cores: the per-pixel vector-matrix product (x - mean) @ cov_inv (flow.py:156) is
+// 2 304 multiply-adds per 192 bytes read -- on the vector ALUs the kernel above runs at a third of the HBM rate.  Here a wave
+// takes its 64 pixels as four tiles of 16 (anic48_mfma_kernel's operand layout): lane (n = lane % 16, g = lane / 16) loads
+// x[16 j + 4 g + e] of pixel n (NCHW: 16 consecutive pixels of a channel per 64-byte segment), the A fragments
+// cov_inv[16 j + 4 g + e][16 t + n] stay in 36 registers, accumulator t holds y[16 t + 4 g + r] of pixel n -- the same channels
+// the lane loaded, so the quadratic form is a register dot product; the lanes' shares are summed with the block's pixels.
+// VEC (H*W a multiple of 4): tile pt takes the pixels 4 n + pt of the wave's 64, so a lane's four tiles are ONE 16-byte load per
+// channel (16 lanes = 256 contiguous bytes) instead of four 4-byte loads that each use half a cache line.
+template <bool VEC>
+__global__ __launch_bounds__(256)
+void logp48_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ cov_inv,
+                        float logdet_cov, float* __restrict__ scratch, int nblk, int HW)
+{
+    constexpr int C = 48;
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    f32x4 a[3][3], mu[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        mu[j] = *(const f32x4*)(mean + 16 * j + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[t][j][e] = cov_inv[(16 * j + 4 * g + e) * C + 16 * t + n];
+    }
+    const float cst = logdet_cov + (float)C * 1.8378770664093453f;
+    float lik = 0.f;
+    f32x4 xq[3][4];                           // VEC: [j][e] = the channel's values at the lane's four pixels
+    if (VEC) {
+        const int p0 = blockIdx.x * LOGP_PIX + wave * 64 + 4 * n;
+        const float* zp = z + (int64_t)b * C * HW + (p0 < HW ? p0 : 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[j][e] = *(const f32x4*)(zp + (int64_t)(16 * j + 4 * g + e) * HW);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int p = blockIdx.x * LOGP_PIX + wave * 64 + (VEC ? 4 * n + pt : pt * 16 + n);
+        const bool live = p < HW;
+        const float* zp = z + (int64_t)b * C * HW + (live ? p : 0);
+        f32x4 x[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = (VEC ? xq[j][e][pt] : zp[(int64_t)(16 * j + 4 * g + e) * HW]) - mu[j][e];
+                x[j][e] = live ? v : 0.f;
+            }
+        float q = 0.f;
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = mfma16p(a[t][j][e], x[j][e], acc[t]);      // three independent chains interleaved
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q = fmaf(acc[t][r], x[t][r], q);
+        lik += -0.5f * q;
+        if (live && g == 0) lik += -0.5f * cst;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lik += __shfl_xor(lik, o, 64);
+    if (lane == 0) red[wave] = lik;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[(int64_t)b * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // out = wa[b]*za + wb[b]*zb: two rounded products and one rounded sum, as torch evaluates (1-a)*z1 + a*z2
 __global__ __launch_bounds__(256)
 void lerp_kernel(const float* __restrict__ za, const float* __restrict__ zb, const float* __restrict__ wa,
@@ -274,7 +347,9 @@ int ifl_k_logp(const float* z, const float* mean, const float* cov_inv, float lo
 {
     int nblk = ifl_cdiv(HW, LOGP_PIX);
     dim3 grid(nblk, B), block(256);
-    if (C == 48) hipLaunchKernelGGL((logp_kernel<48>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
+    if (C == 48 && cov_inv && HW % 4 == 0 && ((uintptr_t)z & 15) == 0) hipLaunchKernelGGL(logp48_mfma_kernel<true>, grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, HW);
+    else if (C == 48 && cov_inv) hipLaunchKernelGGL(logp48_mfma_kernel<false>, grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, HW);
+    else if (C == 48) hipLaunchKernelGGL((logp_kernel<48>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
     else if (C == 12) hipLaunchKernelGGL((logp_kernel<12>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
     else hipLaunchKernelGGL((logp_kernel<0>), grid, block, 0, st, z, mean, cov_inv, logdet_cov, scratch, nblk, C, HW);
     IFL_LAUNCH_CHECK();

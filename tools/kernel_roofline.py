@@ -117,7 +117,7 @@ def main():
             cov = model.cov_shift_1 @ model.cov_shift_1.T
             ci, mu = torch.inverse(cov).contiguous(), (model.mean_shift_1 * torch.ones(48, device=dev)).contiguous()
             s = raw_time(lambda: L.ifl_gaussian_logp(P(z), P(mu), P(ci), 0.0, P(scr), P(lo), B, 48, 40, 40, st))
-            add("logp_kernel<48> + ld_finalize (full covariance)", "Gaussian.logp flow.py:146-157", "hbm", 4 * z.numel(), s, size)
+            add("logp48_mfma_kernel + ld_finalize (full covariance)", "Gaussian.logp flow.py:146-157", "hbm", 4 * z.numel(), s, size)
             if B > 256:
                 continue
             # one FlowStep without coupling: the fused ActNorm + 1x1 conv kernel, timed inside the library
