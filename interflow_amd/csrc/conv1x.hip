@@ -6,7 +6,7 @@
 // FlowAffineCouplingsAblation.py:219-233,248-256, plus fFeatures' ActNorm / ReLU / 1x1 / ActNorm / ReLU) with 36
 // multiplications per 4x4 outputs, input channel and output channel instead of the direct form's 144 (F(2x2,3x3): 64):
 //   Y = A^T [ sum_ci U[co][ci] (.) V[ci] ] A,   U = G g G^T (host, float64 -> fp32, pack.py),   V = B^T d B
-// for every 4x4 output tile and its 6x6 input window d (Lavin & Gray's matrices for the points 0, +-1, +-2, inf).  For each of
+// for every 4x4 output tile and its 6x6 input window d (Toom-Cook matrices for the points 0, +-3/4, +-3/2, inf: ifl_common.h).  For each of
 // the 36 positions (i, jc) of the transformed domain the sum over input channels is a GEMM
 //   M[co][tile] = U[co][ci] V[ci][tile]     (fp32 throughout; the result differs from the direct form by fp32 rounding only:
 //                                            tests/test_wino_numerics.py, tests/test_gpu_parity.py).
@@ -40,34 +40,41 @@ constexpr int XBUF = 36 * 32 * IFL_XCH;       // floats per V image (one tile gr
 constexpr int XLDS = 8 * 4 * 16 * 64;         // LDS floats: the epilogue's exchange (8 waves x 4 x f32x16 per lane) > two V images
 constexpr int XRD = 9;                        // weight ring depth (positions)
 constexpr int XSLOT = 16 * 64;                // floats per exchanged f32x16 (all lanes)
+static_assert(3 * XBUF <= XLDS, "three V images in the kernel's LDS array");
+#ifndef IFL_X_AUX_W
+#define IFL_X_AUX_W 0                         // cache policy bits of the weight loads (experiments: 2 = nt, 16 = sc1)
+#endif
+#ifndef IFL_X_AUX_V
+#define IFL_X_AUX_V 0                         // ... of the image loads
+#endif
 
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 y) {
     return f32x4{__builtin_fmaf(s, x[0], y[0]), __builtin_fmaf(s, x[1], y[1]), __builtin_fmaf(s, x[2], y[2]), __builtin_fmaf(s, x[3], y[3])};
 }
 
-// B^T x for one column / row of six values (B^T of F(4x4,3x3), points 0, +-1, +-2, inf):
-//   t0 = 4 x0 - 5 x2 + x4        t1,2 = (x4 - 4 x2) +- (x3 - 4 x1)        t3,4 = (x4 - x2) +- 2 (x3 - x1)        t5 = 4 x1 - 5 x3 + x5
+// B^T x for one column / row of six values (points 0, +-a, +-b, inf; ifl_common.h):
+//   t0 = AB x0 - (A+B) x2 + x4      t1,2 = (x4 - B x2) +- a (x3 - B x1)      t3,4 = (x4 - A x2) +- b (x3 - A x1)      t5 = AB x1 - (A+B) x3 + x5
 // `get(k)` yields x_k, `put(k, v)` consumes t_k; even inputs are fetched and folded first, so few values are live at a time.
 template <class Get, class Put>
 __device__ __forceinline__ void bt6(Get get, Put put) {
     f32x4 a, c;
     {
         const f32x4 x2 = get(2), x4 = get(4);
-        a = fma4(-4.f, x2, x4);
-        c = x4 - x2;
-        put(0, fma4(4.f, get(0), fma4(-5.f, x2, x4)));
+        a = fma4(-IFL_W4_B, x2, x4);
+        c = fma4(-IFL_W4_A, x2, x4);
+        put(0, fma4(IFL_W4_AB, get(0), fma4(-IFL_W4_ApB, x2, x4)));
     }
     f32x4 b, e;
     {
         const f32x4 x1 = get(1), x3 = get(3);
-        b = fma4(-4.f, x1, x3);
-        e = x3 - x1;
-        put(5, fma4(4.f, x1, fma4(-5.f, x3, get(5))));
+        b = fma4(-IFL_W4_B, x1, x3);
+        e = fma4(-IFL_W4_A, x1, x3);
+        put(5, fma4(IFL_W4_AB, x1, fma4(-IFL_W4_ApB, x3, get(5))));
     }
-    put(1, a + b);
-    put(2, a - b);
-    put(3, fma4(2.f, e, c));
-    put(4, fma4(-2.f, e, c));
+    put(1, fma4(IFL_W4_a, b, a));
+    put(2, fma4(-IFL_W4_a, b, a));
+    put(3, fma4(IFL_W4_b, e, c));
+    put(4, fma4(-IFL_W4_b, e, c));
 }
 
 __device__ __forceinline__ void st16(float* p, const f32x16& v) {
@@ -92,22 +99,23 @@ __device__ __forceinline__ void ld16(const float* p, f32x16& v) {
 }
 
 // One direction of the output transform for a wave that holds three consecutive of the six values (blk 0: 0,1,2; blk 1:
-// 3,4,5).  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  keep[0..1] are this block's parts of the two
-// outputs it finishes (outputs 2 blk, 2 blk + 1), send[0..1] its parts of the partner's two outputs.
+// 3,4,5).  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 A A B B 0; 0 a^3 -a^3 b^3 -b^3 1] (ifl_common.h).  keep[0..1] are this block's
+// parts of the two outputs it finishes (outputs 2 blk, 2 blk + 1), send[0..1] its parts of the partner's two outputs.
 __device__ __forceinline__ void at_part(int blk, const f32x16& m0, const f32x16& m1, const f32x16& m2,
                                         f32x16& k0, f32x16& k1, f32x16& s0, f32x16& s1)
 {
     if (blk == 0) {
-        s0 = m1 + m2;            // output 2
-        s1 = m1 - m2;            // output 3
-        k0 = m0 + s0;            // output 0
-        k1 = s1;                 // output 1
+        const f32x16 sm = m1 + m2, df = m1 - m2;
+        s0 = sm * IFL_W4_A;      // output 2
+        s1 = df * IFL_W4_a3;     // output 3
+        k0 = m0 + sm;            // output 0
+        k1 = df * IFL_W4_a;      // output 1
     } else {
         s0 = m0 + m1;            // output 0
-        f32x16 df = m0 - m1;
-        s1 = df * 2.f;           // output 1
-        k0 = s0 * 4.f;           // output 2
-        k1 = df * 8.f + m2;      // output 3
+        const f32x16 df = m0 - m1;
+        s1 = df * IFL_W4_b;      // output 1
+        k0 = s0 * IFL_W4_B;      // output 2
+        k1 = df * IFL_W4_b3 + m2;      // output 3
     }
 }
 
@@ -196,58 +204,82 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    // weights: [half][block][sub-chunk][position][lane][4], contiguous per wave; the ring's last loads run past the wave's
-    // region into the next one / the pad behind the field
+    // Loads are buffer loads: a descriptor in scalar registers + a constant per-lane offset + a scalar offset per load, so the
+    // loop holds no 64-bit address arithmetic on the vector ALU and no address registers; reads past a descriptor's end
+    // (the ring's last refills, IFL_X_AUX experiments) return zeros.
+    // weights: [half][block][sub-chunk][position][lane][4], contiguous per wave
     const float* wp = prm + off.w1x[net] + (int64_t)(mh * 4 + bi * 2 + bj) * (XN * 9 * 256);       // wave-uniform
-    const unsigned wl = lane * 16;            // bytes
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, XN * 9 * 1024, 0x00020000);
+    const int wl = lane * 16;                 // bytes
     f32x4 wq[XRD];
-#pragma unroll
-    for (int k = 0; k < XRD; ++k) wq[k] = *(const f32x4*)((const char*)(wp + k * 256) + wl);
+    auto load_w = [&](int idx) {              // fragment idx = sub-chunk * 9 + position of this wave's stream
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wl, idx * 1024, IFL_X_AUX_W));
+    };
 
-    // image staging: 2304 16-byte pieces per sub-chunk, piece tid + 512 k for k = 0..4 (k = 4: waves 0-3 only)
-    const float* vgrp = vg + (int64_t)grp * (XN * XBUF);                   // uniform
-    const unsigned vl = tid * 16;             // bytes
-    const bool five = wave < 4;
-    f32x4 sv[5];
-    auto load_v = [&](int s) {
+    // image staging: 36,864 bytes per sub-chunk, the same split for every wave (wave-dependent branches around loads make the
+    // compiler's wait counts pessimistic): 16-byte pieces tid + 512 k for k = 0..3, then 8 bytes at 32768 + 8 tid.
+    // TWO register sets: an image is loaded two sub-chunks before it is stored to LDS (a load under full traffic takes about
+    // as long as one sub-chunk's 4,608 matrix-pipe cycles: with one set the later of a SIMD's two waves waited for its image
+    // in every sub-chunk and the loop ran at that latency, profiles/r03_notes.md).
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(vg + (int64_t)grp * (XN * XBUF)), 0, XN * XBUF * 4, 0x00020000);
+    const int vl = tid * 16, vl8 = 4 * 8192 + tid * 8;             // bytes
+    struct Img { f32x4 v[4]; f32x2 t; };
+    Img svA, svB;
+    auto load_v = [&](Img& d, int s) {
 #ifdef IFL_EXP_NOWIN
         return;
 #endif
-        const char* src = (const char*)(vgrp + s * XBUF);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)(src + k * 8192 + vl);
-        if (five) sv[4] = *(const f32x4*)(src + 4 * 8192 + vl);
+        for (int k = 0; k < 4; ++k)
+            d.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vl, s * (XBUF * 4) + k * 8192, IFL_X_AUX_V));
+        d.t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrs, vl8, s * (XBUF * 4), IFL_X_AUX_V));
     };
-    auto store_v = [&](float* V) {
+    auto store_v = [&](float* V, const Img& d) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(f32x4*)((char*)V + k * 8192 + vl) = sv[k];
-        if (five) *(f32x4*)((char*)V + 4 * 8192 + vl) = sv[4];
+        for (int k = 0; k < 4; ++k) *(f32x4*)((char*)V + k * 8192 + vl) = d.v[k];
+        *(f32x2*)((char*)V + vl8) = d.t;
     };
 #ifdef IFL_EXP_NOWIN
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sv[k] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(tid + k);
+    for (int k = 0; k < 4; ++k) svA.v[k] = svB.v[k] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(tid + k);
+    svA.t = svB.t = f32x2{1.f, 2.f} * (float)tid;
 #endif
 
+    // Three LDS images in rotation: sub-chunk s multiplies image s (buffer s % 3), stores image s + 2 (register set s & 1,
+    // loaded two sub-chunks earlier) and loads image s + 4 into that set.  Image s + 1 has been complete since the previous
+    // barrier, so the first two positions' operands of sub-chunk s + 1 are read BEFORE its barrier and its first MFMAs need no
+    // LDS round trip after it; the barrier itself (all reads of image s - 1 over -> its buffer may be overwritten; image
+    // s + 1 visible) sits behind the first two position pairs, where the matrix pipe has work queued.
     XT_STAMP(0);
     long long xt_bar = 0, xt_pass = 0;
-    load_v(0);
-    store_v(lds);
-    load_v(1);
+    f32x4 xb[2];
+    load_v(svA, 0);
+    load_v(svB, 1);
+    store_v(lds, svA);
+    store_v(lds + XBUF, svB);
+    // loads in the order of the steady state at the head of a sub-chunk -- ring positions 0, 1; an image; ring 2..8 -- because
+    // the compiler's wait counts at the loop head are the stricter of the entry's and the back edge's (with the ring filled
+    // first, every second sub-chunk waited for ALL outstanding loads); pinned, the scheduler otherwise reorders them
+    load_v(svA, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
+    load_v(svB, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 2; k < XRD; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
+    __syncthreads();
+    xb[0] = *(const f32x4*)(lds + vrd);
+    xb[1] = *(const f32x4*)(lds + vrd + 256);
 
-    auto sub_chunk = [&](int s, auto par) {
-        constexpr int PAR = decltype(par)::value;
-        const float* vr = lds + PAR * XBUF + vrd;
-        { long long c0 = XT_CLK();
-        __syncthreads();                      // V[PAR] complete; V[PAR ^ 1] free
-        xt_bar += XT_CLK() - c0; }
-        const float* wc = wp + (int64_t)s * (9 * 256);
-        f32x4 xb[2];                          // one pair of positions at a time: read right after the previous pair's MFMAs are issued
-        xb[0] = *(const f32x4*)(vr);
-        xb[1] = *(const f32x4*)(vr + 256);
-        { long long c0 = XT_CLK();
-        if (s + 1 < XN) store_v(lds + (PAR ^ 1) * XBUF);
-        if (s + 2 < XN) load_v(s + 2);
-        xt_pass += XT_CLK() - c0; }
+    // STORE / LOAD: whether images s + 2 / s + 4 exist, NEXT: whether sub-chunk s + 1 does -- compile-time, so that the loop
+    // body has no branch around a load (the last four sub-chunks are peeled)
+    auto sub_chunk = [&](int s, auto bi_, Img& sv, auto st, auto ld, auto nx) {
+        constexpr int BI = decltype(bi_)::value;
+        constexpr bool STORE = decltype(st)::value, LOAD = decltype(ld)::value, NEXT = decltype(nx)::value;
+        const float* vr = lds + BI * XBUF + vrd;
+        const float* vn = lds + ((BI + 1) % 3) * XBUF + vrd;
+        float* vw = lds + ((BI + 2) % 3) * XBUF;
 #pragma unroll
         for (int pp = 0; pp < 5; ++pp) {      // position pairs (0,1) (2,3) (4,5) (6,7) and 8 alone
             const int p0 = 2 * pp, np = pp < 4 ? 2 : 1;
@@ -255,26 +287,54 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int u = 0; u < np; ++u)
-                    acc[p0 + u] = mfma32(wq[(PAR * 9 + p0 + u) % XRD][e], xb[u][e], acc[p0 + u]);
+#ifdef IFL_EXP_NOMFMA
+                    acc[p0 + u][e] = __builtin_fmaf(wq[p0 + u][e], xb[u][e], acc[p0 + u][e]);
+#else
+                    acc[p0 + u] = mfma32(wq[p0 + u][e], xb[u][e], acc[p0 + u]);
+#endif
+#ifndef IFL_EXP_NOW
 #pragma unroll
-            for (int u = 0; u < np; ++u)
-                wq[(PAR * 9 + p0 + u) % XRD] = *(const f32x4*)((const char*)(wc + (p0 + u + XRD) * 256) + wl);
+            for (int u = 0; u < np; ++u) wq[p0 + u] = load_w((s + 1) * 9 + p0 + u);
+#endif
             if (pp < 4) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int p = p0 + 2 + u;
                     if (p < 9) xb[u] = *(const f32x4*)(vr + ((p / 3) * 6 + p % 3) * 256);
                 }
+            } else if (NEXT) {
+                xb[0] = *(const f32x4*)(vn);
+                xb[1] = *(const f32x4*)(vn + 256);
+            }
+            if (pp == 1) {
+                { long long c0 = XT_CLK();
+                __syncthreads();
+                xt_bar += XT_CLK() - c0; }
+                long long c0 = XT_CLK();
+                if (STORE) store_v(vw, sv);
+                if (LOAD) load_v(sv, s + 4);
+                xt_pass += XT_CLK() - c0;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     XT_STAMP(1);
     const long long xt_c1 = XT_CLK();
-    for (int s = 0; s < XN; s += 2) {
-        sub_chunk(s, std::integral_constant<int, 0>{});
-        sub_chunk(s + 1, std::integral_constant<int, 1>{});
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    using Yes = std::true_type; using No = std::false_type;
+    static_assert(XN == 40, "the tail below is written for 40 sub-chunks");
+    for (int s = 0; s < 36; s += 6) {
+        sub_chunk(s, T0{}, svA, Yes{}, Yes{}, Yes{});
+        sub_chunk(s + 1, T1{}, svB, Yes{}, Yes{}, Yes{});
+        sub_chunk(s + 2, T2{}, svA, Yes{}, Yes{}, Yes{});
+        sub_chunk(s + 3, T0{}, svB, Yes{}, Yes{}, Yes{});
+        sub_chunk(s + 4, T1{}, svA, Yes{}, Yes{}, Yes{});
+        sub_chunk(s + 5, T2{}, svB, Yes{}, Yes{}, Yes{});
     }
+    sub_chunk(36, T0{}, svA, Yes{}, No{}, Yes{});
+    sub_chunk(37, T1{}, svB, Yes{}, No{}, Yes{});
+    sub_chunk(38, T2{}, svA, No{}, No{}, Yes{});
+    sub_chunk(39, T0{}, svB, No{}, No{}, No{});
     XT_PUT(5, (unsigned long long)xt_bar); XT_PUT(6, (unsigned long long)(XT_CLK() - xt_c1)); XT_PUT(7, (unsigned long long)xt_pass);
     XT_STAMP(2);
     (void)xt_bar; (void)xt_pass; (void)xt_c1;

@@ -115,6 +115,34 @@ static inline IflWGeom ifl_wgeom(int B, int H, int W) {
 // tiles per workgroup.  The GEMM kernel reads the conditioning features already transformed (V = B^T d B per tile and
 // channel), as one 36,864-byte LDS image per (group of 32 tiles, sub-chunk of 8 channels):
 // vg[group][40 sub-chunks][36 positions][2 quads][32 tiles][4 channels] (conv1x.hip). ---------------------------------------
+// Interpolation points of every F(4x4,3x3) transform in the library: 0, +-a, +-b, infinity with a = 3/4, b = 3/2 (Lavin &
+// Gray's 0, +-1, +-2, inf until round 3).  The fp32 rounding error of the 320-channel convolution is half of what the
+// integer points give (rms 4.9e-7 against 1.0e-6 of the output's rms, max 8e-7 against 4e-6; tools/exp_wino_points.py), and
+// every constant below is exact in fp32.  With A = a^2, B = b^2 and the rows of B^T scaled to a leading coefficient of one:
+//   B^T x:  t0 = AB x0 - (A+B) x2 + x4    t1,2 = (x4 - B x2) +- a (x3 - B x1)    t3,4 = (x4 - A x2) +- b (x3 - A x1)
+//           t5 = AB x1 - (A+B) x3 + x5
+//   G:      [1/(AB), 0, 0];  [1, +-a, A] / (2A(A-B));  [1, +-b, B] / (2B(B-A));  [0, 0, 1]           (ifl_wino4_G)
+//   A^T m:  y0 = m0 + (m1+m2) + (m3+m4)   y1 = a (m1-m2) + b (m3-m4)   y2 = A (m1+m2) + B (m3+m4)
+//           y3 = a^3 (m1-m2) + b^3 (m3-m4) + m5
+#define IFL_W4_a 0.75f
+#define IFL_W4_b 1.5f
+#define IFL_W4_A 0.5625f      // a^2
+#define IFL_W4_B 2.25f        // b^2
+#define IFL_W4_AB 1.265625f   // a^2 b^2
+#define IFL_W4_ApB 2.8125f    // a^2 + b^2
+#define IFL_W4_a3 0.421875f   // a^3
+#define IFL_W4_b3 3.375f      // b^3
+template <class T>
+static inline __host__ __device__ void ifl_wino4_G(T G[6][3]) {
+    const T a = (T)0.75, b = (T)1.5, A = a * a, B = b * b;
+    const T da = (T)1 / (2 * A * (A - B)), db = (T)1 / (2 * B * (B - A));
+    G[0][0] = (T)1 / (A * B); G[0][1] = 0; G[0][2] = 0;
+    G[1][0] = da; G[1][1] = a * da; G[1][2] = A * da;
+    G[2][0] = da; G[2][1] = -a * da; G[2][2] = A * da;
+    G[3][0] = db; G[3][1] = b * db; G[3][2] = B * db;
+    G[4][0] = db; G[4][1] = -b * db; G[4][2] = B * db;
+    G[5][0] = 0; G[5][1] = 0; G[5][2] = 1;
+}
 #define IFL_XCH 8             // channels per sub-chunk
 struct IflXGeom { int H, W, TH, TW, ntiles; };      // ntiles = B * TH * TW
 static inline __host__ __device__ IflXGeom ifl_xgeom(int B, int H, int W) {

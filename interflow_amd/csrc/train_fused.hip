@@ -231,8 +231,8 @@ void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
             const int co = mh * 32 + o, ci = d.real0 + sc * 8 + hh * 4 + e;
             const int pi = 3 * bi + il, pj = 3 * bj + jl;
             const float* g = d.src + ((int64_t)co * cin_real + ci) * 9;
-            const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double G[6][3];
+            ifl_wino4_G(G);
             double u = 0.0;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -246,8 +246,8 @@ void pack_table_kernel(const ifl_pack_desc* __restrict__ table)
             const int p = (int)((idx >> 6) / IFL_FT);
             const int pi = p / 6, pj = p - pi * 6;
             const float* g = d.src + ((int64_t)co * cin_real + d.real0 + ci) * 9;
-            const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double G[6][3];
+            ifl_wino4_G(G);
             double u = 0.0;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -292,22 +292,22 @@ void wino4_kmajor_kernel(const float* __restrict__ src, int C, int64_t plane_str
 #pragma unroll
             for (int r = 0; r < 6; ++r)
                 x[r] = (cin && 4 * tr + r <= g.H + 1) ? *(const f32x4*)(base + (int64_t)(r * W2 + c) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
-            Tc[0][c] = 4.f * x[0] - 5.f * x[2] + x[4];
-            Tc[1][c] = (x[4] - 4.f * x[2]) + (x[3] - 4.f * x[1]);
-            Tc[2][c] = (x[4] - 4.f * x[2]) - (x[3] - 4.f * x[1]);
-            Tc[3][c] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
-            Tc[4][c] = (x[4] - x[2]) - 2.f * (x[3] - x[1]);
-            Tc[5][c] = 4.f * x[1] - 5.f * x[3] + x[5];
+            Tc[0][c] = IFL_W4_AB * x[0] - IFL_W4_ApB * x[2] + x[4];
+            Tc[1][c] = (x[4] - IFL_W4_B * x[2]) + IFL_W4_a * (x[3] - IFL_W4_B * x[1]);
+            Tc[2][c] = (x[4] - IFL_W4_B * x[2]) - IFL_W4_a * (x[3] - IFL_W4_B * x[1]);
+            Tc[3][c] = (x[4] - IFL_W4_A * x[2]) + IFL_W4_b * (x[3] - IFL_W4_A * x[1]);
+            Tc[4][c] = (x[4] - IFL_W4_A * x[2]) - IFL_W4_b * (x[3] - IFL_W4_A * x[1]);
+            Tc[5][c] = IFL_W4_AB * x[1] - IFL_W4_ApB * x[3] + x[5];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4* x = Tc[i];
-            T[i][0] = 4.f * x[0] - 5.f * x[2] + x[4];
-            T[i][1] = (x[4] - 4.f * x[2]) + (x[3] - 4.f * x[1]);
-            T[i][2] = (x[4] - 4.f * x[2]) - (x[3] - 4.f * x[1]);
-            T[i][3] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
-            T[i][4] = (x[4] - x[2]) - 2.f * (x[3] - x[1]);
-            T[i][5] = 4.f * x[1] - 5.f * x[3] + x[5];
+            T[i][0] = IFL_W4_AB * x[0] - IFL_W4_ApB * x[2] + x[4];
+            T[i][1] = (x[4] - IFL_W4_B * x[2]) + IFL_W4_a * (x[3] - IFL_W4_B * x[1]);
+            T[i][2] = (x[4] - IFL_W4_B * x[2]) - IFL_W4_a * (x[3] - IFL_W4_B * x[1]);
+            T[i][3] = (x[4] - IFL_W4_A * x[2]) + IFL_W4_b * (x[3] - IFL_W4_A * x[1]);
+            T[i][4] = (x[4] - IFL_W4_A * x[2]) - IFL_W4_b * (x[3] - IFL_W4_A * x[1]);
+            T[i][5] = IFL_W4_AB * x[1] - IFL_W4_ApB * x[3] + x[5];
         }
     } else {                                  // dM = A dY A^T of the 4x4 block whose corner is image pixel (4 tr, 4 tc)
         const float* base = sp + ((int64_t)(b * (g.H + 2) + 4 * tr + 1) * W2 + 4 * tc + 1) * C;
@@ -320,20 +320,20 @@ void wino4_kmajor_kernel(const float* __restrict__ src, int C, int64_t plane_str
             for (int r = 0; r < 4; ++r)
                 y[r] = (cin && 4 * tr + r < g.H) ? *(const f32x4*)(base + (int64_t)(r * W2 + c) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
             Tc[0][c] = y[0];
-            Tc[1][c] = (y[0] + y[2]) + (y[1] + y[3]);
-            Tc[2][c] = (y[0] + y[2]) - (y[1] + y[3]);
-            Tc[3][c] = (y[0] + 4.f * y[2]) + (2.f * y[1] + 8.f * y[3]);
-            Tc[4][c] = (y[0] + 4.f * y[2]) - (2.f * y[1] + 8.f * y[3]);
+            Tc[1][c] = (y[0] + IFL_W4_A * y[2]) + (IFL_W4_a * y[1] + IFL_W4_a3 * y[3]);
+            Tc[2][c] = (y[0] + IFL_W4_A * y[2]) - (IFL_W4_a * y[1] + IFL_W4_a3 * y[3]);
+            Tc[3][c] = (y[0] + IFL_W4_B * y[2]) + (IFL_W4_b * y[1] + IFL_W4_b3 * y[3]);
+            Tc[4][c] = (y[0] + IFL_W4_B * y[2]) - (IFL_W4_b * y[1] + IFL_W4_b3 * y[3]);
             Tc[5][c] = y[3];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4* y = Tc[i];
             T[i][0] = y[0];
-            T[i][1] = (y[0] + y[2]) + (y[1] + y[3]);
-            T[i][2] = (y[0] + y[2]) - (y[1] + y[3]);
-            T[i][3] = (y[0] + 4.f * y[2]) + (2.f * y[1] + 8.f * y[3]);
-            T[i][4] = (y[0] + 4.f * y[2]) - (2.f * y[1] + 8.f * y[3]);
+            T[i][1] = (y[0] + IFL_W4_A * y[2]) + (IFL_W4_a * y[1] + IFL_W4_a3 * y[3]);
+            T[i][2] = (y[0] + IFL_W4_A * y[2]) - (IFL_W4_a * y[1] + IFL_W4_a3 * y[3]);
+            T[i][3] = (y[0] + IFL_W4_B * y[2]) + (IFL_W4_b * y[1] + IFL_W4_b3 * y[3]);
+            T[i][4] = (y[0] + IFL_W4_B * y[2]) - (IFL_W4_b * y[1] + IFL_W4_b3 * y[3]);
             T[i][5] = y[3];
         }
     }
@@ -356,8 +356,8 @@ void wino4_dw_kernel(const float* __restrict__ dU, int64_t rows_total, const ifl
     const int64_t row = idx / IFL_FT; const int ci = idx - row * IFL_FT;
     const ifl_wino4_dst d = table[row >> 6];
     const int co = row & 63;
-    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float G[6][3];
+    ifl_wino4_G(G);
     float t[3][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -403,9 +403,9 @@ void wino4_untile_kernel(const float* __restrict__ Y, float* __restrict__ out, i
 #pragma unroll
         for (int i = 0; i < 6; ++i) m[i] = Y[((int64_t)(i * 6 + j) * C + c) * T + tile];
         t[0][j] = (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
-        t[1][j] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
-        t[2][j] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
-        t[3][j] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
+        t[1][j] = IFL_W4_a * (m[1] - m[2]) + IFL_W4_b * (m[3] - m[4]);
+        t[2][j] = IFL_W4_A * (m[1] + m[2]) + IFL_W4_B * (m[3] + m[4]);
+        t[3][j] = (IFL_W4_a3 * (m[1] - m[2]) + IFL_W4_b3 * (m[3] - m[4])) + m[5];
     }
     float* base = out + ((int64_t)b * C + c) * g.H * g.W;
 #pragma unroll
@@ -415,9 +415,9 @@ void wino4_untile_kernel(const float* __restrict__ Y, float* __restrict__ out, i
         const float* m = t[r];
         f32x4 o;
         o[0] = (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
-        o[1] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
-        o[2] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
-        o[3] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
+        o[1] = IFL_W4_a * (m[1] - m[2]) + IFL_W4_b * (m[3] - m[4]);
+        o[2] = IFL_W4_A * (m[1] + m[2]) + IFL_W4_B * (m[3] + m[4]);
+        o[3] = (IFL_W4_a3 * (m[1] - m[2]) + IFL_W4_b3 * (m[3] - m[4])) + m[5];
         float* dst = base + (int64_t)y * g.W + 4 * tc;
         if (4 * tc + 3 < g.W && (g.W & 3) == 0) *(f32x4*)dst = o;
         else

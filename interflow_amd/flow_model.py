@@ -284,17 +284,51 @@ class DegradationNet(nn.Module):
 
 
 # ------------------------------------------------------------------------------------- prior
+def _h2d(t, device):
+    """Host tensor -> device without a host/device synchronisation (pinned staging + non_blocking copy; a pageable copy blocks
+    the host until the device has drained the stream)."""
+    if t.device.type != "cpu" or device.type == "cpu":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class Gaussian:
     """flow.py:138-161 on the HIP path."""
     Log2PI = float(np.log(2 * np.pi))
 
     @staticmethod
-    def logp(mean, cov, x):
+    def inverse_of(cov_fn, key, mean, C, device, tag=""):
+        """(mean [C], cov_inv [C, C], ln|cov|) for the inference kernel, on `device`, cached per VERSION of the parameter
+        `key` the covariance is made of (`cov_fn()` builds it): flow.py:146-149 inverts the covariance on every call, here
+        the inverse (float64 `inv_ex` on the device, rounded once) and the log-determinant are computed when the parameter
+        has changed and kept, so a loss evaluation in steady state reads nothing back from the device (one read of the
+        log-determinant per parameter update; the kernel takes it by value)."""
+        ver = (key._version, mean._version if isinstance(mean, torch.Tensor) else 0)
+        ent = key.__dict__.get("_ifl_prior")             # kept on the parameter object itself, like the packed weights
+        if ent is not None and ent[0] == ver and ent[1] == device and ent[2] == tag:
+            return ent[3:]
+        c64 = cov_fn().detach().to(device=device, dtype=torch.float64)
+        inv = torch.linalg.inv_ex(c64)[0].to(torch.float32).contiguous()
+        logdet = float(torch.linalg.slogdet(c64)[1])
+        mean_t = mean.detach().to(device=device, dtype=torch.float32).reshape(-1)
+        if mean_t.numel() == 1:
+            mean_t = mean_t.expand(C)
+        mean_t = mean_t.contiguous()
+        key.__dict__["_ifl_prior"] = (ver, device, tag, mean_t, inv, logdet)
+        return mean_t, inv, logdet
+
+    @staticmethod
+    def logp(mean, cov, x, key=None):
+        """key: the parameter `cov` was computed from, when the caller has one -- the inverse is then cached per parameter
+        version (`inverse_of`); without it the covariance is inverted on the host on every call, as the reference does."""
         if torch.is_grad_enabled() and (x.requires_grad or (cov is not None and (cov.requires_grad or mean.requires_grad))):
             from . import train_flow
             return train_flow.gaussian_logp(mean, cov, x)              # differentiable (training path)
         if mean is None and cov is None:
             return hip.gaussian_logp(x)
+        if key is not None:
+            mean_t, cov_inv, logdet = Gaussian.inverse_of(lambda: cov, key, mean, x.shape[1], x.device)
+            return hip.gaussian_logp(x, mean_t, cov_inv, logdet)
         # torch.inverse / torch.slogdet of the 48x48 covariance: tiny host-side linear algebra, as the reference
         cov_c = cov.detach().to("cpu", torch.float32)
         cov_inv = torch.inverse(cov_c)
@@ -376,6 +410,12 @@ class InterpFlow(nn.Module):
         means = [m * torch.ones(self.C, device=m.device) for m in self.mean_shifts]
         return means, covs
 
+    def _prior(self, i, device):
+        """(mean [C], cov_inv, ln|cov|) of class i's prior (flow_model.py:138-141: cov = cov_shift cov_shift^T, mean =
+        mean_shift * 1), cached per version of the two parameters: no host read in steady state."""
+        c = self.cov_shifts[i]
+        return Gaussian.inverse_of(lambda: torch.matmul(c, c.T), c, self.mean_shifts[i], self.C, device)
+
     def _class_table(self, device):
         """The class scales as a device tensor (uploaded once per device: no host round trip per loss evaluation)."""
         t = self.__dict__.get("_classes_dev")
@@ -389,13 +429,13 @@ class InterpFlow(nn.Module):
         log-density `ll` the objective uses).  The reference ASSIGNS ll[label == c] per class, and the 'X' (label 0) rows are
         written again by the second loop, so a label-0 sample ends with the standard-normal log-density even when 0 is one
         of the classes.  No host tests on device data here (the reference's `any()` branch is a `where`)."""
-        label = label.to(z.device)
-        means, covs = self._shifted(z.device)
-        if torch.is_grad_enabled() and (z.requires_grad or any(c.requires_grad for c in covs) or any(m.requires_grad for m in means)):
+        label = _h2d(label, z.device)
+        if torch.is_grad_enabled() and (z.requires_grad or any(c.requires_grad for c in self.cov_shifts) or any(m.requires_grad for m in self.mean_shifts)):
             from . import train_flow
+            means, covs = self._shifted(z.device)
             ll_all = train_flow.gaussian_logp_classes(torch.stack(means), torch.stack(covs), z)                  # (n, cls), all classes at once
         else:
-            ll_all = torch.stack([Gaussian.logp(means[i], covs[i], z) for i in range(len(self.classes))], dim=1)  # (n, cls)
+            ll_all = torch.stack([hip.gaussian_logp(z, *self._prior(i, z.device)) for i in range(len(self.classes))], dim=1)  # (n, cls)
         mask_label = self._class_table(z.device)[None, :] == label.reshape(-1, 1)
         ll = torch.zeros(z.shape[0], device=z.device)
         for i in range(len(self.classes)):
@@ -413,7 +453,14 @@ class InterpFlow(nn.Module):
         ll_all, mask_label, ll = self._class_loglik(z, label)
         ll_ib = ll_all / float(pixels)
         ll_ib = torch.log_softmax(ll_ib, dim=1)
-        ll_ib = torch.masked_select(ll_ib, mask_label)
+        if label.device.type == "cpu" and z.device.type != "cpu":
+            # labels that live on the host (train.py:69 builds them there): the selected (sample, class) pairs are known without
+            # asking the device, so the selection is a gather with host-made indices instead of masked_select, whose output
+            # size is a device-to-host read
+            rows, cols = np.nonzero(np.asarray(self.classes)[None, :] == label.numpy().reshape(-1, 1))
+            ll_ib = ll_ib[_h2d(torch.from_numpy(rows), z.device), _h2d(torch.from_numpy(cols), z.device)]
+        else:
+            ll_ib = torch.masked_select(ll_ib, mask_label)
         objective = objective + ll
         nll = (-objective) / float(np.log(2.) * pixels)
         if isinstance(epses, list):
@@ -460,11 +507,10 @@ class InterpFlow(nn.Module):
 
     def get_pdf(self, z: torch.Tensor, scales: list):
         pixels = int(z.size(2) * z.size(3))
-        means, covs = self._shifted(z.device)
         ll = []
         for scale in scales:
             index = self.classes.index(scale)
-            ll.append(Gaussian.logp(means[index], covs[index], z) / float(np.log(2.) * pixels))
+            ll.append(hip.gaussian_logp(z, *self._prior(index, z.device)) / float(np.log(2.) * pixels))
         return torch.stack(ll, dim=0).reshape(-1)
 
     def get_shifted_info(self):

@@ -248,7 +248,7 @@ class Split2d(nn.Module):
             ll[dom_x] = Gaussian.logp(None, None, eps[dom_x].contiguous())
         if bool(dom_y.any()):
             cov_shifted = self.I + torch.matmul(self.cov_shift, self.cov_shift.T)
-            ll[dom_y] = Gaussian.logp(mean=self.mean_shift, cov=cov_shifted, x=eps[dom_y].contiguous())
+            ll[dom_y] = Gaussian.logp(mean=self.mean_shift, cov=cov_shifted, x=eps[dom_y].contiguous(), key=self.cov_shift)
         return ll
 
     def forward(self, input, logdet=0., reverse=False, eps_std=None, eps=None, ft=None, y_onehot=None):

@@ -72,8 +72,21 @@ def _pack_conv1_wino(wt, zoff):
     return np.ascontiguousarray(u.transpose(7, 2, 3, 6, 0, 4, 1, 5)).reshape(-1)
 
 
-_WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
-                     [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], np.float64)
+def wino4_matrices(a=0.75, b=1.5):
+    """(A^T [4,6], G [6,3], B^T [6,6]) of F(4x4,3x3) for the interpolation points 0, +-a, +-b, infinity, float64, the rows of
+    B^T scaled to a leading coefficient of one -- the library's choice a = 3/4, b = 3/2 and scaling (csrc/ifl_common.h,
+    IFL_W4_*; tools/exp_wino_points.py for why these points)."""
+    A, B = a * a, b * b
+    da, db = 1 / (2 * A * (A - B)), 1 / (2 * B * (B - A))
+    G = np.array([[1 / (A * B), 0, 0], [da, a * da, A * da], [da, -a * da, A * da],
+                  [db, b * db, B * db], [db, -b * db, B * db], [0, 0, 1]], np.float64)
+    BT = np.array([[A * B, 0, -(A + B), 0, 1, 0], [0, -a * B, -B, a, 1, 0], [0, a * B, -B, -a, 1, 0],
+                   [0, -b * A, -A, b, 1, 0], [0, b * A, -A, -b, 1, 0], [0, A * B, 0, -(A + B), 0, 1]], np.float64)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, a, -a, b, -b, 0], [0, A, A, B, B, 0], [0, a ** 3, -a ** 3, b ** 3, -b ** 3, 1]], np.float64)
+    return AT, G, BT
+
+
+_WINO4_G = wino4_matrices()[1]
 
 
 def _pack_conv1_wino4(wt, zoff):

@@ -167,12 +167,20 @@ def _uninitialised_actnorms(model):
     return todo
 
 
-def init_actnorm(model, gt, low_res, dist=None, lr_enc=None, src: int = 0):
+def init_actnorm(model, gt, low_res, dist=None, lr_enc=None, src: int = 0, add_gt_noise: bool = True):
     """Data-dependent ActNorm initialisation (FlowActNorms.py:29-43, and inside every flow.Conv2d, flow.py:57-63) as a step
     of its own, BEFORE the first optimizer step: one gradient-enabled forward whose result is dropped (each rank initialises
-    from its own batch, as the reference's first training forward does), then every replica takes rank `src`'s parameters,
-    so that data-parallel replicas start identical (only gradients are averaged afterwards).  Returns the number of ActNorms
-    that were initialised; 0 (and no forward, no collective) when there was nothing to do on any rank."""
+    from its own batch, as the reference's first training forward does -- with the quantisation noise of flow_model.py:107-110
+    unless add_gt_noise=False), then every replica takes rank `src`'s parameters, so that data-parallel replicas start
+    identical (only gradients are averaged afterwards).  Returns the number of ActNorms that were initialised; 0 (and no
+    forward) when there was nothing to do on any rank.
+
+    The decision is made ONCE: after a call that found nothing to do on any rank, or after an initialisation pass, the model is
+    marked (`model._ifl_actnorm_done`) and later calls return at once -- no collective, no host read.  Every rank sets the mark
+    in the same call, so the replicas keep taking the same branch.  `inited` is never reset by this package; code that resets
+    it by hand must also `del model._ifl_actnorm_done` on every rank."""
+    if model.__dict__.get("_ifl_actnorm_done"):
+        return 0
     todo = _uninitialised_actnorms(model)
     n = len(todo)
     multi = dist is not None and dist.get_world_size() > 1
@@ -182,15 +190,17 @@ def init_actnorm(model, gt, low_res, dist=None, lr_enc=None, src: int = 0):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         n = int(flag.item())
     if n == 0:
+        model.__dict__["_ifl_actnorm_done"] = True
         return 0
     with torch.enable_grad():
         if lr_enc is None:
             lr_enc = model.arch.rrdbPreprocessing(gt)
-        model(low_res, gt, lr_enc=lr_enc, add_gt_noise=False, calc_loss=False)
+        model(low_res, gt, lr_enc=lr_enc, add_gt_noise=add_gt_noise, calc_loss=False)
     for m in todo:
         m.inited = True
     if multi:
         broadcast_parameters(model, dist, src)
+    model.__dict__["_ifl_actnorm_done"] = True
     return n
 
 
@@ -229,6 +239,7 @@ class TableAdam(torch.optim.Optimizer):
         dev = params[0].device
         rows = []
         steps = []
+        step_cache = {}
         for p in params:
             if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() or p.device != dev:
                 raise RuntimeError("TableAdam: float32 contiguous parameters and gradients on one device")
@@ -237,7 +248,11 @@ class TableAdam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             else:
-                steps.append(float(st["step"]))
+                t = st["step"]                                  # one host read per distinct cell (all parameters share one)
+                k = t.data_ptr() if torch.is_tensor(t) else None
+                if k is None or k not in step_cache:
+                    step_cache[k] = float(t)
+                steps.append(step_cache[k])
             n, CH = p.numel(), hip.ADAM_CHUNK
             for o in range(0, n, CH):
                 rows.append((p.data_ptr() + 4 * o, p.grad.data_ptr() + 4 * o, st["exp_avg"].data_ptr() + 4 * o,
@@ -355,7 +370,7 @@ def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_
         reducer.zero_grad()
         reducer.defer = True                    # the hooks only collect; finish() launches the all-reduces after the decision
     else:
-        optimizer.zero_grad()
+        optimizer.zero_grad(set_to_none=False)  # in place: TableAdam's table is keyed on the gradients' addresses
     try:
         with accumulate_into_grad():
             loss.backward()                                                             # train.py:129
@@ -466,7 +481,7 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
     parameters nor make the replicas diverge."""
     dist = reducer.dist if reducer is not None else None
     if model.training:
-        init_actnorm(model, gt, low_res, dist)
+        init_actnorm(model, gt, low_res, dist, add_gt_noise=add_gt_noise)
     if lr_enc is None:                                                                  # (given: EncoderPrefetcher's features of gt)
         lr_enc = model.arch.rrdbPreprocessing(gt, outputs=FLOW_FEATURES)                # train.py:72 (the maps the L=2 flow reads)
     from .train_fused import shared_ft_grad
@@ -514,7 +529,7 @@ def _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, 
         if reducer is not None:
             reducer.zero_grad()
         else:
-            optimizer.zero_grad()                                                       # :128
+            optimizer.zero_grad(set_to_none=False)                                      # :128 (in place: see TableAdam)
         from .train_fused import accumulate_into_grad
         with accumulate_into_grad():
             loss.backward()                                                             # :129

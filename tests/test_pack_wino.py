@@ -9,9 +9,7 @@ import torch.nn.functional as F
 pytest.importorskip("interflow_amd.hip")
 from interflow_amd import hip, pack  # noqa: E402
 
-BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
-                [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], np.float64)
-AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], np.float64)
+AT4, _, BT4 = pack.wino4_matrices()        # points 0, +-3/4, +-3/2, inf (csrc/ifl_common.h)
 BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
 AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
 

@@ -17,12 +17,8 @@ sys.path.insert(0, ROOT)
 from interflow_amd import synth  # noqa: E402
 from oracle import interflow_oracle as O  # noqa: E402
 
-# Lavin & Gray, interpolation points 0, +-1, +-2, inf
-BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
-                [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], np.float64)
-G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
-               [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], np.float64)
-AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], np.float64)
+from interflow_amd import pack  # noqa: E402
+AT4, G4, BT4 = pack.wino4_matrices()        # the library's points 0, +-3/4, +-3/2, inf (csrc/ifl_common.h)
 BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
 G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
 AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
