@@ -70,15 +70,17 @@ def cpu_baseline(sd_np, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)                 # 100 steps = 2.3 s of timed region
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="patches per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true",
-                    help="after the timed region also measure two secondary figures (never `value`): conditioning reuse "
-                         "between encode and decode, and the bf16 variant of the dominant convolution")
-    ap.add_argument("--breakdown", action="store_true",
-                    help="after the timed region also run the steps on one stream and time every kernel (extra fields)")
+                    help="after the timed region also measure the bf16 variant of the dominant convolution (never `value`)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary fields measured AFTER the timed region by default: `cond_reuse` (encode + decode with "
+                         "one shared conditioning preparation), `serial_schedule` (the steps on one stream: the dominant kernel "
+                         "alone) and `kernels_ms_per_step` (every kernel of one step timed)")
+    ap.add_argument("--breakdown", action="store_true", help="(kept for old command lines: the breakdown is on by default)")
     args = ap.parse_args()
 
     rank, local_rank, world = shard.dist_env()
@@ -130,7 +132,9 @@ def main():
         err = float((xr - x).abs().max())
         if not os.environ.get("IFL_BENCH_TIMING_ONLY"):      # kernel timing experiments with deliberately wrong arithmetic
             assert np.isfinite(err) and err < 1e-3, f"decode(encode(x)) differs from x by {err}"
-        if args.extras:
+        secondary = not args.no_secondary
+        sec_steps = min(args.steps, 20)
+        if secondary:
             # Secondary figure (never `value`): the conditioning-only part of the coupling networks computed ONCE per
             # step (ifl_cond_prepare) and used by both the encode and the decode of that step, as
             # InterpFlow.weighted_interpolate_image / generate.py do.  Outputs are bit-identical.
@@ -143,7 +147,7 @@ def main():
             step_reuse()
             barrier()
             t2 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(sec_steps):
                 xr2, _ = step_reuse()
             barrier()
             reuse_elapsed = shard.max_over_ranks(time.perf_counter() - t2, dist, dev)
@@ -167,20 +171,20 @@ def main():
             bf16 = {"elapsed": bf_elapsed, "dom_ms": b_ms, "dom_n": b_n,
                     "round_trip_err": float((ob[2] - x).abs().max()),
                     "z_rel_err_vs_fp32": float((ob[0] - z).abs().max() / z.abs().max())}
-        if args.breakdown:
+        if secondary:
             # (1) the same steps with everything on ONE stream: kernels strictly one after another, so the dominant
             #     kernel's duration is free of time-sharing with the per-step chain; (2) one step with every kernel timed
             hip.set_schedule(aux_stream=0, groups=1)
             step(); torch.cuda.synchronize()
             hip.prof_enable([hip.K_CONV1_FT_L1])
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(sec_steps):
                 step()
             torch.cuda.synchronize()
             serial_elapsed = time.perf_counter() - t1
             s_ms, s_n = hip.prof_read(hip.K_CONV1_FT_L1)
             hip.prof_enable([])
-            serial = {"ms_per_step": serial_elapsed / args.steps * 1e3, "dominant_avg_launch_ms": s_ms / max(s_n, 1)}
+            serial = {"ms_per_step": serial_elapsed / sec_steps * 1e3, "dominant_avg_launch_ms": s_ms / max(s_n, 1), "steps": sec_steps}
             names = (("conv1_ft_l1", hip.K_CONV1_FT_L1), ("conv1_ft_l2", hip.K_CONV1_FT_L2),
                      ("conv3_f", hip.K_CONV3_F), ("conv1_finish", hip.K_CONV1_FINISH),
                      ("conv3_enc", hip.K_CONV3_ENC), ("conv3_dec", hip.K_CONV3_DEC), ("anic", hip.K_ANIC))
@@ -256,9 +260,9 @@ def main():
 
             "roundtrip_max_abs_err": err,
         }
-        if args.extras:
-            res["cond_reuse"] = {"value": world * B * args.steps / reuse_elapsed, "unit": "patches/s",
-                                 "ms_per_step": reuse_elapsed / args.steps * 1e3,
+        if secondary:
+            res["cond_reuse"] = {"value": world * B * sec_steps / reuse_elapsed, "unit": "patches/s",
+                                 "ms_per_step": reuse_elapsed / sec_steps * 1e3, "steps": sec_steps,
                                  "note": "secondary, NOT the metric: same encode+decode, but the z-independent first conv of "
                                          "the coupling networks is computed once per step for both passes "
                                          "(ifl_cond_prepare); 0.54 of the reference's FLOPs are executed"}

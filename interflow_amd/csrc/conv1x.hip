@@ -199,10 +199,6 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
     const int vrd = ((3 * bi) * 6 + 3 * bj) * 256 + h * 128 + j * 4;      // V[(3 bi + il) * 6 + 3 bj + jl][quad h][tile j]: + (il * 6 + jl) * 256
 
     f32x16 acc[9];
-#pragma unroll
-    for (int p = 0; p < 9; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     // Loads are buffer loads: a descriptor in scalar registers + a constant per-lane offset + a scalar offset per load, so the
     // loop holds no 64-bit address arithmetic on the vector ALU and no address registers; reads past a descriptor's end
@@ -253,21 +249,31 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
     XT_STAMP(0);
     long long xt_bar = 0, xt_pass = 0;
     f32x4 xb[2];
-    load_v(svA, 0);
-    load_v(svB, 1);
-    store_v(lds, svA);
-    store_v(lds + XBUF, svB);
-    // loads in the order of the steady state at the head of a sub-chunk -- ring positions 0, 1; an image; ring 2..8 -- because
-    // the compiler's wait counts at the loop head are the stricter of the entry's and the back edge's (with the ring filled
-    // first, every second sub-chunk waited for ALL outstanding loads); pinned, the scheduler otherwise reorders them
-    load_v(svA, 2);
-    __builtin_amdgcn_sched_barrier(0);
+    // Prologue: every load at once -- images 0 and 1 into registers the accumulators will use (they are cleared afterwards),
+    // then, in the order of the steady state at the head of a sub-chunk, image 2; ring positions 0, 1; image 3; ring 2..8 --
+    // one exposed round trip.  The order matters beyond that: the compiler's wait counts at the loop head are the stricter of
+    // the entry's and the back edge's (with the ring filled first, every second sub-chunk waited for ALL outstanding loads);
+    // pinned with sched_barrier, the scheduler otherwise reorders the loads.
+    {
+        Img t0, t1;
+        load_v(t0, 0);
+        load_v(t1, 1);
+        load_v(svA, 2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
-    load_v(svB, 3);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 2; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
+        load_v(svB, 3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 2; k < XRD; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
+        for (int k = 2; k < XRD; ++k) { wq[k] = load_w(k); __builtin_amdgcn_sched_barrier(0); }
+        store_v(lds, t0);
+        store_v(lds + XBUF, t1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     __syncthreads();
     xb[0] = *(const f32x4*)(lds + vrd);
     xb[1] = *(const f32x4*)(lds + vrd + 256);

@@ -63,14 +63,49 @@ def join_side_streams():
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
+# Data parallel: `on_ready(params, final)` (training.GradientAllReducer.mark_ready) is called right behind every such add, on the
+# stream it was queued on, so that the reducer can launch a bucket's all-reduce while the backward pass goes on.  A step may run
+# several flow passes over the same parameters (the consistency term: three encodes and a decode): every gradient-enabled
+# forward of a level notes one contribution that is still due, every backward settles one, and a gradient is final -- may be
+# exchanged -- when none is left.
+_on_ready = None
+_contrib = {}
+
+
+def reset_contributions():
+    """Start of a training step: graphs dropped without a backward pass (a skipped step) leave contributions behind."""
+    _contrib.clear()
+
+
+def _note_forward(params):
+    if params:
+        _contrib[id(params[0])] = _contrib.get(id(params[0]), 0) + 1
+
+
+def _settle(params):
+    """One contribution to these parameters' gradients has just been queued; tell the reducer (final: it was the last)."""
+    if not params:
+        return
+    k = id(params[0])
+    n = _contrib.get(k, 1) - 1
+    _contrib[k] = max(n, 0)
+    if _on_ready is not None:
+        _on_ready(params, n <= 0)
+
+
 class accumulate_into_grad:
+    def __init__(self, on_ready=None):
+        self.on_ready = on_ready
+
     def __enter__(self):
-        global _direct_grad
+        global _direct_grad, _on_ready
         self.prev, _direct_grad = _direct_grad, True
+        self.prev_cb, _on_ready = _on_ready, self.on_ready
 
     def __exit__(self, *exc):
-        global _direct_grad
+        global _direct_grad, _on_ready
         _direct_grad = self.prev
+        _on_ready = self.prev_cb
         join_side_streams()
 
 
@@ -590,6 +625,8 @@ class _LevelFn(torch.autograd.Function):
         ctx.hub = hub
         L = _lib()
         _mark("before level")
+        if any(ctx.needs_input_grad[9:]):
+            _note_forward(plan.params)
         plan.busy = True
         ctx.lease = _Lease(plan)
         ctx.ft_ring = ft_ring                           # the backward reads it (weight gradients of the first convolutions)
@@ -694,7 +731,9 @@ class _LevelFn(torch.autograd.Function):
             torch.sum(t, dim=2, out=o)
         if direct:
             torch._foreach_add_([p.grad for p in plan.params], plan.grad_views)
+            _settle(plan.params)                                       # (on the stream the add was queued on)
             return [None] * len(plan.params)
+        _settle(())
         return [g.clone() for g in plan.grad_views]
 
 
@@ -708,6 +747,8 @@ class _StackGroups(torch.autograd.Function):
         n = len(params) // k
         ctx.k, ctx.n, ctx.params = k, n, params
         ctx.set_materialize_grads(False)                  # a stack nobody differentiates leaves its parameters' .grad alone
+        if any(ctx.needs_input_grad[1:]):
+            _note_forward(params)
         return tuple(torch.stack(params[g * n:(g + 1) * n]) for g in range(k))
 
     @staticmethod
@@ -718,7 +759,11 @@ class _StackGroups(torch.autograd.Function):
         if _direct_grad and all(p.grad is not None and p.grad.dtype == g.dtype for p, g in need):
             if need:
                 torch._foreach_add_([p.grad for p, _ in need], [g for _, g in need])
+            _settle(params)
             return (None,) * (1 + len(params))
+        k = id(params[0]) if params else None
+        if k in _contrib:
+            _contrib[k] = max(_contrib[k] - 1, 0)
         out = [None] * len(params)
         for i, p in enumerate(params):
             if ctx.needs_input_grad[1 + i] and grads[i // n] is not None:

@@ -132,6 +132,8 @@ class _EncoderFn(torch.autograd.Function):
                 for p, v in zip(plan.params, plan.views):
                     if not (v.is_contiguous() and p.grad.is_contiguous()):
                         p.grad.add_(v)
+                if TF._on_ready is not None:
+                    TF._on_ready(plan.params, True)                        # one encoder pass per step: these gradients are final
                 grads = [None] * len(plan.params)
             else:
                 grads = [v.clone() for v in plan.views]

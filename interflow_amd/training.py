@@ -37,26 +37,55 @@ def _drain_for_gloo(dist, t):
 
 
 class GradientAllReducer:
+    """Gradients as views into flat buckets, each all-reduced asynchronously as soon as its last gradient exists.
+
+    Two ways a gradient becomes "ready":
+      * autograd accumulates it into .grad -> the post-accumulate hook (`_on_grad`): the layer-by-layer path and the few
+        parameters outside the level drivers (the prior's, the stacked ActNorm / LU parameters when not in direct mode);
+      * the fused level / encoder drivers add a whole level's ~290 gradients into the .grad views themselves with one
+        multi-tensor add and hand autograd None, so no hook fires: they call `mark_ready(params)` right behind that add, on
+        the stream it ran on (`train_fused.accumulate_into_grad(on_ready=...)`); the collective is issued from that stream,
+        i.e. ordered after the add, and runs beside the rest of the backward pass (the next level's chain).
+    A bucket whose parameters never all become ready is reduced by `finish()`.  After the FIRST finished step the parameters
+    that received nothing (the reference's dead modules) are moved behind the live ones into buckets of
+    their own (`rebucket`), so that from the second step on every bucket of live parameters is launched during the backward
+    pass; a "dead" parameter that does receive a gradient later is still reduced, by `finish()`."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], dist=None, bucket_bytes: int = 32 << 20):
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
+        self.bucket_bytes = bucket_bytes
         seen, self.params = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:        # the model registers aliases of the same tensors
                 seen.add(id(p))
                 self.params.append(p)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.defer = False            # True: nothing is launched before finish() (train_step's late_check)
+        self.launched_early = 0       # buckets launched before finish() in the current step (tests, logs)
+        self.launch_log = []          # (bucket index, "early" | "finish") of the current step, in launch order
+        self._rebucketed = False
         # buckets in reverse registration order: roughly the order in which backward produces the gradients
+        self._build(list(reversed(self.params)))
+
+    def _build(self, ordered, groups=None, cut_after=()):
+        """ordered: parameters in bucket order; groups: optional list of lists that must not share a bucket; cut_after: ids of
+        parameters behind which a bucket that is at least half full is closed (the end of a set that became ready together)."""
         self.buckets: List[dict] = []
-        cur, size = [], 0
-        for p in reversed(self.params):
-            n = p.numel() * p.element_size()
-            if cur and (size + n > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+        for plist in (groups if groups is not None else [ordered]):
+            cur, size = [], 0
+            for p in plist:
+                n = p.numel() * p.element_size()
+                if cur and (size + n > self.bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                    self._close(cur)
+                    cur, size = [], 0
+                cur.append(p)
+                size += n
+                if id(p) in cut_after and 2 * size >= self.bucket_bytes:
+                    self._close(cur)
+                    cur, size = [], 0
+            if cur:
                 self._close(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += n
-        if cur:
-            self._close(cur)
         self._bucket_of, self._offset_of = {}, {}
         for bi, b in enumerate(self.buckets):
             o = 0
@@ -64,17 +93,22 @@ class GradientAllReducer:
                 self._bucket_of[id(p)] = bi
                 self._offset_of[id(p)] = o          # (looked up by every gradient hook: no linear search per call)
                 o += p.numel()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self.defer = False            # True: the hooks launch nothing; finish() reduces every bucket (train_step's late_check)
-        self.zero_grad()
+        self._ready, self._order, self._group = set(), {}, 0
+        self.zero_grad(reattach=True)
 
     def _close(self, plist):
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
-        self.buckets.append({"params": list(plist), "flat": flat, "pending": 0, "work": None, "launched": False})
+        self.buckets.append({"params": list(plist), "flat": flat, "pending": 0, "work": None, "launched": False, "index": len(self.buckets)})
 
     def zero_grad(self, reattach: bool = False):
         """Zero the buckets; attach every parameter's .grad as a view into its bucket (once: autograd accumulates into an
         existing .grad in place, and `_on_grad` brings back a tensor that was replaced; `reattach` forces it again)."""
+        if getattr(self, "_pending_rebucket", None) and self.rebucket():
+            return                                # (once, at the start of the second step: the new buckets are zeroed and attached)
+        self._ready = set()
+        self._order, self._group = {}, 0
+        self.launched_early = 0
+        self.launch_log = []
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
@@ -85,13 +119,24 @@ class GradientAllReducer:
                     o += p.numel()
                 b["attached"] = True
 
-    def _launch(self, b):
+    def _launch(self, b, early=False):
         b["launched"] = True
+        self.launch_log.append((b["index"], "early" if early else "finish"))
+        self.launched_early += int(early)
         if os.environ.get("IFL_DEBUG_REDUCER"):
-            print(f"[reducer rank {self.dist.get_rank() if self.dist else 0}] launch bucket {self.buckets.index(b)} n={b['flat'].numel()} pending={b['pending']}", flush=True)
+            print(f"[reducer rank {self.dist.get_rank() if self.dist else 0}] launch bucket {b['index']} n={b['flat'].numel()} pending={b['pending']}", flush=True)
         if self.dist is not None and self.world > 1:
             _drain_for_gloo(self.dist, b["flat"])
             b["work"] = self.dist.all_reduce(b["flat"], async_op=True)
+
+    def _count(self, p):
+        if id(p) in self._ready:              # a second contribution to a gradient that was already counted (several passes)
+            return None
+        self._ready.add(id(p))
+        self._order[id(p)] = (self._group, len(self._order))      # when it became ready: the first step's order makes the buckets
+        b = self.buckets[self._bucket_of[id(p)]]
+        b["pending"] -= 1
+        return b
 
     def _on_grad(self, p):
         b = self.buckets[self._bucket_of[id(p)]]
@@ -99,9 +144,27 @@ class GradientAllReducer:
             o = self._offset(b, p)                               # autograd replaced the tensor: copy it back into the bucket
             b["flat"][o:o + p.numel()].copy_(p.grad.reshape(-1))
             p.grad = b["flat"][o:o + p.numel()].view_as(p)
-        b["pending"] -= 1
-        if b["pending"] == 0 and not b["launched"] and not self.defer:
-            self._launch(b)
+        if self._count(p) is not None and b["pending"] == 0 and not b["launched"] and not self.defer:
+            self._launch(b, early=True)
+
+    def mark_ready(self, params, final: bool = True):
+        """The gradients of `params` have been added into their .grad views by work queued on the CURRENT stream (the fused
+        drivers' multi-tensor add); final=False: more contributions follow in this backward pass (several flow passes over
+        the same parameters), so nothing is counted yet.  Buckets that are complete are all-reduced from this stream."""
+        if not final:
+            return
+        self._group += 1
+        touched = {}
+        for p in params:
+            if id(p) not in self._bucket_of:
+                continue
+            b = self._count(p)
+            if b is not None:
+                touched[b["index"]] = b
+        self._group += 1                      # (gradients that autograd's hooks report in between form a set of their own)
+        for b in touched.values():
+            if b["pending"] == 0 and not b["launched"] and not self.defer:
+                self._launch(b, early=True)
 
     def _offset(self, b, p):
         return self._offset_of[id(p)]
@@ -116,6 +179,29 @@ class GradientAllReducer:
                 b["work"].wait()
             if self.world > 1:
                 b["flat"].div_(self.world)
+        if not self._rebucketed and not self.defer:
+            self._rebucketed = True
+            self._pending_rebucket = ([p for p in self.params if id(p) not in self._ready], dict(self._order))
+
+    def rebucket(self):
+        """Between steps (after the optimizer has read the gradients): the live parameters in the order in which their gradients
+        became ready in the first step -- the prior's, the last flow level's, the first level's, the stacked ActNorm / LU
+        parameters, the encoder's -- with a bucket closed where a set that became ready together ends (if it is at least half
+        full), and the parameters that received nothing in buckets of their own behind them.  Registration order mixes a
+        level's large weights with the small parameters whose gradients arrive last, which held every bucket back until the
+        end of the backward pass.  Returns the number of parameters without a gradient."""
+        pend = getattr(self, "_pending_rebucket", None)
+        self._pending_rebucket = None
+        if not pend:
+            return 0
+        dead, order = pend
+        if len(dead) == len(self.params):
+            return 0
+        dead_ids = {id(p) for p in dead}
+        live = sorted((p for p in self.params if id(p) not in dead_ids), key=lambda p: order[id(p)])
+        cut = {id(p) for p, q in zip(live, live[1:] + [None]) if q is None or order[id(q)][0] != order[id(p)][0]}
+        self._build(None, groups=[live, [p for p in self.params if id(p) in dead_ids]], cut_after=cut)
+        return max(len(dead), 1)
 
     def remove(self):
         for h in self._hooks:
@@ -372,7 +458,7 @@ def _finish_late(model, optimizer, reducer, scheduler, step, loss, nll_loss, ib_
     else:
         optimizer.zero_grad(set_to_none=False)  # in place: TableAdam's table is keyed on the gradients' addresses
     try:
-        with accumulate_into_grad():
+        with accumulate_into_grad(reducer.mark_ready if reducer is not None else None):
             loss.backward()                                                             # train.py:129
     finally:
         if reducer is not None:
@@ -494,6 +580,8 @@ def train_step(model, optimizer, gt, low_res, labels, ib_lambda: float = 1.0, re
 
 def _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, scheduler, step, add_gt_noise, consistency_lambda,
                      interp, interpolate_weight, lr_enc, late_check, host_sync, dist):
+    from .train_fused import reset_contributions
+    reset_contributions()
     if late_check:
         z, logdet = model(low_res, gt, lr_enc=lr_enc, add_gt_noise=add_gt_noise, calc_loss=False)    # :73
         nll, ib_loss = model.loss_terms(z, logdet, int(gt.size(2) * gt.size(3)), labels)             # :74
@@ -531,7 +619,7 @@ def _train_step_body(model, optimizer, gt, low_res, labels, ib_lambda, reducer, 
         else:
             optimizer.zero_grad(set_to_none=False)                                      # :128 (in place: see TableAdam)
         from .train_fused import accumulate_into_grad
-        with accumulate_into_grad():
+        with accumulate_into_grad(reducer.mark_ready if reducer is not None else None):
             loss.backward()                                                             # :129
         if reducer is not None:
             reducer.finish()

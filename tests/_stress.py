@@ -9,8 +9,9 @@ from interflow_amd import synth
 SCALES = [2, 4]
 
 
-def stress_fixture(golden_dir):
-    return np.load(os.path.join(golden_dir, "stress_seed1.npz"))
+def stress_fixture(golden_dir, seed=1):
+    """seed 1: the full fixture (32x32, 160x160 batch 2, 512x512 samples); seed 2 (round 3): a third weight seed, 160x160 batch 1."""
+    return np.load(os.path.join(golden_dir, f"stress_seed{seed}.npz"))
 
 
 def stress_state(g):
@@ -53,7 +54,7 @@ def _errs(got, want):
     return float(err.max()) / max(float(np.abs(want).max()), 1e-30), float((err / np.maximum(np.abs(want), max(rms, 1e-30))).max())
 
 
-NOISE_K = 8.0
+NOISE_K = 4.0          # round 2: 8 (the F(4x4,3x3) form on the points 0, +-1, +-2 needed it); round 3's points need less than 3
 
 
 def noise_aware_close(got, ref32, truth64, tol, what=""):

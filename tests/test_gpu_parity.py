@@ -391,7 +391,7 @@ def test_stress_goldens_all_conv1_algorithms(stress, algo):
       x decoded from the REFERENCE's z: internal activations reach |z| ~ 50 while x is in [0, 1], so an absolute error that is
         7e-6 of the flow's dynamic range is 3e-4 of |x|max; float32 itself is at its limit here (the reference's x_rec is 5e-5
         away from a float64 decode of the same z).  Held to the float64 decode with tests/_stress.py:noise_aware_close
-        (1e-4, or 8x the reference's own float32 noise in that quantity)."""
+        (1e-4, or NOISE_K = 4 x the reference's own float32 noise in that quantity; round 2 needed 8)."""
     g, model = stress
     prev = hip.set_conv1_algo(algo)
     try:
@@ -410,7 +410,35 @@ def test_stress_goldens_all_conv1_algorithms(stress, algo):
             elementwise_close(ldr, g[f"{tag}_ldr"], RTOL, f"{tag} logdet rev")
             print(f"stress {tag} algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  logdet {el[0]:.2e}  "
                   f"own round trip {eo[0]:.2e} {eo[1]:.2e}  x(ref z) vs float64 {ex[0]:.2e} {ex[1]:.2e} "
-                  f"[reference's own {nx[0]:.2e} {nx[1]:.2e}]")
+                  f"[reference's own {nx[0]:.2e} {nx[1]:.2e}; allowed {max(RTOL, 4 * nx[0]):.2e} {max(RTOL, 4 * nx[1]):.2e}]")
+    finally:
+        hip.set_conv1_algo(prev)
+
+
+def test_stress_third_seed(golden_dir):
+    """A third weight seed (tests/golden/stress_seed2.npz, made by the reference: IFL_STRESS_SEED=2 make_golden_stress.py), same
+    regime, 160x160: the criteria of test_stress_goldens_all_conv1_algorithms for every form of the bulk convolution."""
+    g = stress_fixture(golden_dir, seed=2)
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: t(v) for k, v in stress_state(g).items()}, strict=True)
+    model = model.eval().to(dev())
+    B, H, xs, fs = (int(v) for v in g["cases"][0])
+    x, feats = _stress_inputs(g, B, H, xs, fs)
+    prev = hip.set_conv1_algo(-1)
+    try:
+        for algo in (hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD, hip.CONV1_DIRECT):
+            hip.set_conv1_algo(algo)
+            z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+            ez = elementwise_close(z, g["s160_z"], RTOL, "seed 2 z")
+            elementwise_close(ld, g["s160_ld"], RTOL, "seed 2 logdet")
+            xo, ldo = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+            eo = _errs_pair(xo, x)
+            assert eo[0] <= RTOL and eo[1] <= 2 * RTOL, eo
+            xr, ldr = model(t(g["s160_z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
+            ex, nx = noise_aware_close(xr, g["s160_xr"], g["s160_xr64"], RTOL, "seed 2 x decoded from the reference's z")
+            elementwise_close(ldr, g["s160_ldr"], RTOL, "seed 2 logdet rev")
+            print(f"stress seed 2 s160 algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  own round trip {eo[0]:.2e} {eo[1]:.2e}  "
+                  f"x(ref z) vs float64 {ex[0]:.2e} {ex[1]:.2e} [reference's own {nx[0]:.2e} {nx[1]:.2e}; allowed {max(RTOL, 4 * nx[0]):.2e} {max(RTOL, 4 * nx[1]):.2e}]")
     finally:
         hip.set_conv1_algo(prev)
 

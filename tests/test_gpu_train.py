@@ -762,3 +762,163 @@ def test_fused_level_decode_with_gradients():
         for k in gfa:
             assert rel(gfb[k], gfa[k]) < 2e-4, (k, rel(gfb[k], gfa[k]))
         assert worst[1] < 2e-4 and med < 2e-5, (worst, med)
+
+
+class _FakeWork:
+    def wait(self):
+        return True
+
+
+class _FakeDist:
+    """Two data-parallel ranks played one after the other in ONE process: the first run RECORDS what it hands to every SUM
+    all-reduce, the second run ADDS the recording of the same call (the two ranks issue their collectives in the same
+    order), so its buffers end up holding rank 0 + rank 1 -- what RCCL would have left on both."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, log=None):
+        self.mode, self.tape, self.pos, self.log = "record", [], 0, log
+
+    def get_world_size(self):
+        return 2
+
+    def get_rank(self):
+        return 0 if self.mode == "record" else 1
+
+    def get_backend(self):
+        return "fake"
+
+    def replay(self):
+        self.mode, self.pos = "replay", 0
+
+    def all_reduce(self, t, op="sum", async_op=False):
+        if op == "max":
+            return _FakeWork()                                  # the collective skip decision: both ranks say "go on"
+        if self.log is not None:
+            self.log.append(("all_reduce", t.numel()))
+        if self.mode == "record":
+            self.tape.append(t.detach().clone())
+        else:
+            assert self.tape[self.pos].shape == t.shape, "the two ranks' collectives do not line up"
+            t.add_(self.tape[self.pos])
+            self.pos += 1
+        return _FakeWork()
+
+    def broadcast(self, t, src):
+        return _FakeWork()
+
+
+def _dp_model(sd_np, frozen):
+    model = InterpFlow(SCALES)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    model.train().to(dev())
+    if frozen:
+        model.arch.set_rrdb_training(False)
+    model.__dict__["_ifl_actnorm_done"] = True                  # synthesised weights: every ActNorm is initialised
+    return model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frozen", [True, False])
+def test_data_parallel_halves_equal_the_full_batch_on_the_real_model(frozen):
+    """SURVEY.md section 8(e) on the real model: two ranks with half of the batch each, run through training.train_step with
+    the bucketed reducer (the second step's buckets: re-ordered by readiness, launched DURING the fused backward pass),
+    leave in every parameter's .grad what one process computes on the whole batch."""
+    from interflow_amd import training
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    B, H = 4, 32
+    gt = torch.from_numpy(synth.synth_images(191, B, H, H)).to(dev())
+    lr = torch.from_numpy(synth.synth_images(192, B, H, H)).to(dev())
+    labels = torch.tensor([2, 4, 4, 2])
+
+    def grads_of(model):
+        return {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.requires_grad and v.grad is not None}
+
+    class _NoStep(torch.optim.SGD):                              # the gradients are what is compared: parameters must not move
+        def step(self, closure=None):
+            return None
+
+    # the whole batch in one process
+    model = _dp_model(sd_np, frozen)
+    red = training.GradientAllReducer(model.parameters(), None)
+    opt = _NoStep([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    for it in range(2):
+        out = training.train_step(model, opt, gt, lr, labels, reducer=red, step=it, add_gt_noise=False)
+        assert not out["skipped"]
+    want = grads_of(model)
+    # two ranks, half of the batch each
+    model = _dp_model(sd_np, frozen)
+    fake = _FakeDist()
+    red = training.GradientAllReducer(model.parameters(), fake, bucket_bytes=8 << 20)
+    opt = _NoStep([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    halves = [(gt[:2], lr[:2], labels[:2]), (gt[2:], lr[2:], labels[2:])]
+    training.train_step(model, opt, *halves[0], reducer=red, step=0, add_gt_noise=False)      # first step: finds the dead parameters
+    early = None
+    for rank, (g_, l_, y_) in enumerate(halves):                # second step: rank 0 records, rank 1 replays
+        if rank == 1:
+            fake.replay()
+        else:
+            fake.tape, fake.pos, fake.mode = [], 0, "record"
+        out = training.train_step(model, opt, g_, l_, y_, reducer=red, step=1, add_gt_noise=False)
+        assert not out["skipped"]
+        log = list(red.launch_log)
+        early = early if early is not None else log
+        assert log == early, "both ranks must launch the same buckets in the same order"
+    assert fake.pos == len(fake.tape) == len(red.buckets)
+    got = grads_of(model)
+    n_early = sum(1 for _, when in early if when == "early")
+    print(f"frozen={frozen}: {len(red.buckets)} buckets, {n_early} launched during the backward pass: {early}")
+    assert n_early >= len(red.buckets) - 2, early               # all but the dead parameters' bucket(s)
+    errs = []
+    for k, w in want.items():
+        scale = float(w.abs().max())
+        if scale == 0:
+            assert float(got[k].abs().max()) == 0, k
+            continue
+        errs.append((float((got[k] - w).abs().max()) / scale, k))
+    errs.sort()
+    print(f"relative gradient difference, two halves vs the whole batch, over {len(errs)} tensors: median {errs[len(errs) // 2][0]:.2e}, "
+          f"95 % {errs[int(0.95 * len(errs))][0]:.2e}, worst {errs[-1][0]:.2e} ({errs[-1][1]})")
+    # the same sums associated differently (4 samples against 2 + 2, float atomics in the weight gradients); an isolated ReLU
+    # whose pre-activation is rounding noise flips between the two runs and moves one gradient row (DESIGN.md section 6b)
+    assert errs[len(errs) // 2][0] < 1e-4 and errs[int(0.95 * len(errs))][0] < 2e-3 and errs[-1][0] < 5e-2, errs[-5:]
+
+
+@pytest.mark.gpu
+def test_reducer_launches_level_two_buckets_before_level_one_backward_ends():
+    """The gradient exchange overlaps the fused backward pass: in the second step every bucket that holds only parameters of the
+    LAST flow level (whose backward runs first) is all-reduced before the first level's chain has been issued, and only the
+    bucket(s) of parameters without a gradient are left to finish()."""
+    from interflow_amd import train_fused, training
+    sd_np = synth.synth_interpflow_state(SCALES, seed=0)
+    model = _dp_model(sd_np, True)
+    events = []
+    fake = _FakeDist(log=events)
+    red = training.GradientAllReducer(model.parameters(), fake, bucket_bytes=8 << 20)
+    opt, _ = training.make_optimizer(model, lr=1e-4)
+    B, H = 2, 32
+    gt = torch.from_numpy(synth.synth_images(91, B, H, H)).to(dev())
+    lr = torch.from_numpy(synth.synth_images(92, B, H, H)).to(dev())
+    labels = torch.tensor([2, 4])
+    training.train_step(model, opt, gt, lr, labels, reducer=red, step=0, add_gt_noise=False)
+    prev = train_fused.MARK
+    train_fused.MARK = lambda name: events.append(("mark", name))
+    try:
+        del events[:]
+        fake.tape, fake.mode = [], "record"
+        training.train_step(model, opt, gt, lr, labels, reducer=red, step=1, add_gt_noise=False)
+    finally:
+        train_fused.MARK = prev
+    names = {id(p): k for k, p in model.named_parameters()}
+    level2 = [b["index"] for b in red.buckets if all(".layers." in names[id(p)] and int(names[id(p)].split(".layers.")[1].split(".")[0]) >= 19
+                                                     for p in b["params"])]
+    assert level2, "no bucket holds level-2 parameters only"
+    bwd_marks = [i for i, e in enumerate(events) if e == ("mark", "level bwd")]
+    assert len(bwd_marks) == 2                                  # level 2's backward chain, then level 1's
+    reduces_before_level1 = sum(1 for e in events[:bwd_marks[1]] if e[0] == "all_reduce")
+    order = [i for i, _ in red.launch_log]
+    print(f"{len(red.buckets)} buckets; level-2-only buckets {level2}; launch order {red.launch_log}; "
+          f"{reduces_before_level1} all-reduces issued before level 1's backward chain")
+    assert red.launched_early >= len(red.buckets) - 2
+    assert reduces_before_level1 >= len(level2) and set(order[:reduces_before_level1]) >= set(level2)

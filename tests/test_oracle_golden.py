@@ -202,6 +202,22 @@ def test_stress_fixture_against_oracle(golden_dir):
         print(tag, "oracle vs reference (max-norm, element-wise): z", e, "x", e2)
 
 
+def test_stress_third_seed_against_oracle(golden_dir):
+    """A third weight seed in the same regime (IFL_STRESS_SEED=2 make_golden_stress.py -> stress_seed2.npz, 160x160, batch 1)."""
+    from tests._stress import elementwise_close, stress_fixture, stress_state
+    g = stress_fixture(golden_dir, seed=2)
+    sd = O.to_torch(stress_state(g))
+    B, H, xs, fs = (int(v) for v in g["cases"][0])
+    x = t(synth.synth_images(xs, B, H, H))
+    feats = {k: t(v) for k, v in synth.synth_features(fs, B, H, H, rms=float(g["ft_rms"])).items()}
+    z, ld = O.flow_encode(x, feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+    elementwise_close(z, g["s160_z"], 1e-4, "seed 2 z")
+    elementwise_close(ld, g["s160_ld"], 1e-5, "seed 2 logdet")
+    xr, ldr = O.flow_decode(t(g["s160_z"]), feats, sd, "flow_upsampler.", torch.zeros(B), test_input_size=H)
+    elementwise_close(xr, g["s160_xr"], 2e-4, "seed 2 x")
+    elementwise_close(ldr, g["s160_ldr"], 1e-5, "seed 2 logdet rev")
+
+
 def test_actnorm_init_fixture_against_oracle(golden_dir, sd_np):
     """The reference's data-dependent ActNorm initialisation (FlowActNorms.py:29-43, flow.py:57-63): all 164 ActNorms zeroed,
     train mode, one encode of a 32x32 batch of 4 -> every bias / logs tensor, z and logdet."""

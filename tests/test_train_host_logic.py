@@ -116,3 +116,52 @@ def test_ft_hub_makes_one_product_after_every_pass():
             d = d.view(nc, 2, 2, 2).flip(0).reshape(d.shape)
         want = want + d
     assert torch.equal(grads[0], first.ft_grad(want))
+
+
+def test_reducer_mark_ready_contributions_and_rebucketing():
+    """training.GradientAllReducer on the CPU, world size 1 (nothing is exchanged; the launch log is what is checked):
+    gradients added by a fused driver become ready through mark_ready (no autograd hook fires for them), a parameter that is
+    written by several passes is final only with the last contribution, and after the first step the parameters that received
+    nothing move into buckets of their own, so that every bucket of live parameters is launched before finish()."""
+    from interflow_amd import training
+    g = torch.Generator().manual_seed(3)
+    live = [torch.nn.Parameter(torch.randn(64, generator=g)) for _ in range(6)]
+    dead = [torch.nn.Parameter(torch.randn(64, generator=g)) for _ in range(2)]
+    params = [live[0], dead[0], live[1], live[2], dead[1], live[3], live[4], live[5]]
+    red = training.GradientAllReducer(params, None, bucket_bytes=3 * 64 * 4)         # three parameters per bucket
+    assert len(red.buckets) == 3
+
+    def step():
+        red.zero_grad()
+        # live[0..2] through autograd (hooks); live[3..5] the way the level drivers do it: two passes add into .grad directly
+        loss = sum((p * p).sum() for p in live[:3])
+        train_fused.reset_contributions()
+        train_fused._note_forward(live[3:])
+        train_fused._note_forward(live[3:])
+        with train_fused.accumulate_into_grad(red.mark_ready):
+            loss.backward()
+            for k in range(2):
+                torch._foreach_add_([p.grad for p in live[3:]], [torch.ones(64) for _ in range(3)])
+                before = red.launched_early
+                train_fused._settle(live[3:])
+                if k == 0:
+                    assert red.launched_early == before, "a gradient that another pass still writes must not be exchanged"
+        early = red.launched_early
+        red.finish()
+        return early
+
+    early1 = step()
+    assert early1 < len(red.buckets)                      # the dead parameters hold their buckets back in the first step
+    assert all(torch.equal(p.grad, 2 * p.detach()) for p in live[:3]) and all(torch.equal(p.grad, torch.full((64,), 2.0)) for p in live[3:])
+    early2 = step()                                       # zero_grad re-buckets: live parameters first, dead ones behind
+    assert [len(b["params"]) for b in red.buckets] == [3, 3, 2]
+    assert {id(p) for p in red.buckets[2]["params"]} == {id(p) for p in dead}
+    assert early2 == 2 and red.launch_log[-1] == (2, "finish")
+    assert all(torch.equal(p.grad, 2 * p.detach()) for p in live[:3]) and all(torch.equal(p.grad, torch.full((64,), 2.0)) for p in live[3:])
+    assert all(float(p.grad.abs().sum()) == 0 for p in dead)
+    # gradients are views into the new buckets
+    for b in red.buckets:
+        o = 0
+        for p in b["params"]:
+            assert p.grad.data_ptr() == b["flat"].data_ptr() + 4 * o
+            o += p.numel()
