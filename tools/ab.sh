@@ -2,7 +2,7 @@
 # A/B runs of bench.py under different environment settings: bash tools/ab.sh "VAR=1 VAR2=3" "VAR=2" ...
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg timeout -k 10 200 python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "
+  env $cfg timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

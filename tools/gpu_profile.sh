@@ -6,12 +6,12 @@
 set -o pipefail
 TAG=${1:-prof}
 shift
-PMC_ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline}
+PMC_ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline --no-secondary}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p "$O"
 
-[ -n "$SKIP_STATS" ] || { timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d "$O/raw_stats" -- python3 bench.py --no-cpu-baseline > "$O/stats.log" 2>&1 \
+[ -n "$SKIP_STATS" ] || { timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d "$O/raw_stats" -- python3 bench.py --no-cpu-baseline --no-secondary --steps 40 > "$O/stats.log" 2>&1 \
   && python3 tools/prof_summary.py "$O/raw_stats" "$O/kernel_stats.csv" --rm || { tail -20 "$O/stats.log"; exit 1; }
 grep '^{' "$O/stats.log" > "$O/bench_under_rocprof.json"; }
 

@@ -8,6 +8,8 @@ and *_counter_collection.csv (--pmc) below the directory and writes, per kernel 
     calls, total_ms, avg_us, min_us, max_us, pct   (from the trace; must agree with rocprofv3's stats table)
     <counter>_avg                                   (mean counter value per dispatch, one column per counter)
 plus VGPR / LDS / grid of the first dispatch.  --rm deletes the raw directory afterwards.
+`vgpr_rocprof` is rocprofv3's VGPR_Count column as it stands: on gfx950 it is HALF of the registers per lane the kernel allocates
+(conv1_ft_wino4_kernel: 124 in round 2's trace, .vgpr_count 245 -> 248 allocated in the code object; 128 for this round's 256).
 """
 import collections
 import csv
@@ -61,7 +63,7 @@ def main():
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct", "stats_calls", "stats_avg_ns",
-                    "stats_pct", "vgpr", "agpr", "lds_bytes", "grid", "wg"] + [c + "_avg_per_dispatch" for c in counters])
+                    "stats_pct", "vgpr_rocprof", "agpr", "lds_bytes", "grid", "wg"] + [c + "_avg_per_dispatch" for c in counters])
         for name, e in sorted(k.items(), key=lambda kv: -kv[1]["tot"]):
             row = [name, e["n"], "%.3f" % (e["tot"] / 1e6), "%.2f" % (e["tot"] / max(e["n"], 1) / 1e3),
                    "%.2f" % ((e["min"] or 0) / 1e3), "%.2f" % (e["max"] / 1e3), "%.2f" % (100.0 * e["tot"] / total)]
