@@ -160,6 +160,22 @@ int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps);
  * Returns the previous setting.  The bf16 variant (IFL_FLOW_BF16_CONV1) always uses the direct form.                */
 int ifl_set_conv1_algo(int algo);
 
+/* The same choice for ONE flow level (1 = the first, 80x80 planes of a 160x160 patch; 2 = every deeper level); ifl_set_conv1_algo
+ * sets all levels.  Why per level: the rounding noise of the F(4x4) form only shows in a decoded image when it enters at the
+ * LAST level -- the decode runs that level first and the remaining steps amplify it; at the first level it adds nothing
+ * measurable (profiles/r03_notes.md).  Environment IFL_CONV1_WINO_L2=0/1/2 sets the deeper levels' default at load.
+ * Returns the level's previous setting; any other `algo` only queries.  No counterpart in the reference.             */
+int ifl_set_conv1_algo_level(int level, int algo);
+
+/* The LAST `nsteps` conditional steps of the LAST flow level are evaluated by `algo` (same codes) whatever the level's setting
+ * is: default 4 steps by F(2x2,3x3).  The decode runs those steps first and every later step amplifies their rounding noise;
+ * 62 % of the noise variance the F(4x4) form adds to a decoded image enters there (86 % in the last 8; profiles/r03_notes.md),
+ * for 2.7 % of a pass.  nsteps = 0 switches it off; a negative nsteps / an algo outside 0..2 leaves that value as it is.
+ * Environment IFL_CONV1_TAIL_STEPS / IFL_CONV1_TAIL_ALGO set the defaults at load.  Returns the previous number of steps.
+ * Like the other ifl_set_* calls: process-wide, not between ifl_cond_prepare and the passes that use its results
+ * (an encode and the decode that inverts it must see the same setting).  No counterpart in the reference.              */
+int ifl_set_conv1_tail(int nsteps, int algo);
+
 /* Algorithm of the coupling networks' last convolution (flow.Conv2dZeros 3x3, flow.py:67-82) in fp32 (no counterpart in the
  * reference): 1 = Winograd F(2x2,3x3) minimal filtering (default; 2.25x fewer multiplications, transforms are additions only),
  * 0 = direct implicit GEMM.  Environment IFL_CONV3_WINO=0/1 sets the default at load.  Any other value only queries.  Returns

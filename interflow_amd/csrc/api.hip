@@ -388,8 +388,11 @@ static int check_layers(const ifl_layer* layers, int n_layers)
 // own stream, forked from and joined back to the caller's stream with events.
 // The auxiliary streams and events are created once per device on first use and kept for the life of the process.
 #define IFL_MAX_GROUPS 4
+#ifndef IFL_CONV1_L2_DEFAULT
+#define IFL_CONV1_L2_DEFAULT 2
+#endif
 #define IFL_P1_CHUNK 4         // level 1: 4 steps x 2 networks = one (network, step) pair per XCD and launch (conv1x.hip)
-#define IFL_P1_CHUNK_L2 8
+#define IFL_P1_CHUNK_L2 6         // deeper levels: 12 F(4x4) steps = two launches of 1 200 workgroups (4.7 rounds), the 4 tail steps one of their own
 namespace {
 int env_int(const char* name, int dflt);
 constexpr int MAX_P1_EVENTS = IFL_MAX_LEVELS * IFL_MAX_COND;
@@ -447,28 +450,57 @@ Sched& sched()
     return s;
 }
 
-// algorithm of the bulk kernel (fp32): 2 = Winograd F(4x4,3x3) (default), 1 = Winograd F(2x2,3x3), 0 = direct implicit GEMM
-int& conv1_algo()
+// algorithm of the bulk kernel (fp32) per flow level: 2 = Winograd F(4x4,3x3), 1 = Winograd F(2x2,3x3), 0 = direct implicit GEMM.
+// Default 2 at the first level; at the deeper levels IFL_CONV1_WINO_L2 (default: see ifl_set_conv1_algo_level in the header).
+int& conv1_algo(int level = 1)
 {
-    static int a = [] { int v = env_int("IFL_CONV1_WINO", 2); return v < 0 || v > 2 ? 2 : v; }();
-    return a;
+    static int a[2] = {[] { int v = env_int("IFL_CONV1_WINO", 2); return v < 0 || v > 2 ? 2 : v; }(),
+                       [] { int v = env_int("IFL_CONV1_WINO_L2", env_int("IFL_CONV1_WINO", IFL_CONV1_L2_DEFAULT)); return v < 0 || v > 2 ? 2 : v; }()};
+    return a[level <= 1 ? 0 : 1];
+}
+
+// The LAST conditional steps of the LAST level by a more accurate form: {number of steps, algorithm}.  The decode runs those
+// steps first, and everything behind them amplifies what they add: in an fp32 emulation of the stack, 62 % of the rounding-noise
+// variance that F(4x4) adds to a decoded image enters in the last 4 of the 32 conditional steps, 86 % in the last 8, and
+// nothing measurable at the first level (profiles/r03_notes.md).  F(2x2) there costs 2.7 % of a pass.
+int* conv1_tail()
+{
+    static int t[2] = {[] { int v = env_int("IFL_CONV1_TAIL_STEPS", 4); return v < 0 ? 0 : v > IFL_MAX_COND ? IFL_MAX_COND : v; }(),
+                       [] { int v = env_int("IFL_CONV1_TAIL_ALGO", 1); return v < 0 || v > 2 ? 1 : v; }()};
+    return t;
 }
 
 // The z-independent work of the conditional steps [s0, s0 + nsteps) of a level (`steps` lists their parameter blocks):
 // both networks' first conv over the conditioning features into the h2 slabs, then fFeatures' last conv -> sf slabs and
 // its log-det sums.
+int conv1_steps(const IflWs& w, const IflLevelWs& lv, float* h2, const float* params, const IflStepList& steps, int nsteps,
+                const IflStepOff& off, int level, int bf16, int algo, hipStream_t st)
+{
+    if (nsteps <= 0) return 0;
+    if (!bf16 && algo == 2) return ifl_k_conv1_ft_wino4(lv.vg, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
+    if (!bf16 && algo == 1) return ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
+    return ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st);
+}
+
+// n_level: conditional steps of the level (the steps [n_level - tail, n_level) of the last level take the tail's algorithm)
 int bulk_steps(const IflWs& w, const IflLevelWs& lv, int s0, const float* params, const IflStepList& steps, int nsteps,
-               const IflStepOff& off, int level, int bf16, float eps, hipStream_t st)
+               const IflStepOff& off, int level, int bf16, float eps, hipStream_t st, int n_level = 0)
 {
     float* h2 = lv.h2 + (int64_t)s0 * lv.h2_step;
     int rc;
     { ProfScope ps(level == 1 ? IFL_K_CONV1_FT_L1 : IFL_K_CONV1_FT_L2, st);
-      if (!bf16 && conv1_algo() == 2)
-          rc = ifl_k_conv1_ft_wino4(lv.vg, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
-      else if (!bf16 && conv1_algo() == 1)
-          rc = ifl_k_conv1_ft_wino(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, w.B, lv.H, lv.W, level, st);
-      else
-          rc = ifl_k_conv1_ft(lv.ft, h2, lv.h2_step, params, steps, nsteps, off, lv.geom, w.B, level, bf16, st); }
+      const int algo = conv1_algo(level), talgo = conv1_tail()[1];
+      int t0 = nsteps;                          // first step of this launch (relative) that belongs to the tail
+      if (level == IFL_MAX_LEVELS && n_level > 0 && !bf16 && talgo != algo) {
+          t0 = n_level - conv1_tail()[0] - s0;
+          t0 = t0 < 0 ? 0 : t0 > nsteps ? nsteps : t0;
+      }
+      rc = conv1_steps(w, lv, h2, params, steps, t0, off, level, bf16, algo, st);
+      if (!rc && t0 < nsteps) {
+          IflStepList tail{};
+          for (int s = t0; s < nsteps; ++s) tail.off[s - t0] = steps.off[s];
+          rc = conv1_steps(w, lv, h2 + (int64_t)t0 * lv.h2_step, params, tail, nsteps - t0, off, level, bf16, talgo, st);
+      } }
     if (rc) return rc;
     ProfScope ps(IFL_K_CONV3_F, st);
     if (conv3_algo() == 1 || bf16)
@@ -537,7 +569,7 @@ int launch_phase1(const IflWs& w, int lvl, const CondPlan& plan, const float* pa
         const int s0 = ci * chunk, s1 = s0 + chunk < n ? s0 + chunk : n;
         IflStepList sub{};
         for (int s = s0; s < s1; ++s) sub.off[s - s0] = plan.list[lvl].off[s];
-        int rc = bulk_steps(w, lv, s0, params, sub, s1 - s0, off, lvl + 1, bf16, eps, st);
+        int rc = bulk_steps(w, lv, s0, params, sub, s1 - s0, off, lvl + 1, bf16, eps, st, n);
         if (rc) return rc;
         if (ev) IFL_HIP(hipEventRecord(ev[lvl * IFL_MAX_COND + ci], st));
     }
@@ -671,8 +703,23 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
 
 extern "C" int ifl_set_conv1_algo(int algo)
 {
-    int prev = conv1_algo();
-    if (algo >= 0 && algo <= 2) conv1_algo() = algo;
+    int prev = conv1_algo(1);
+    if (algo >= 0 && algo <= 2) conv1_algo(1) = conv1_algo(2) = algo;
+    return prev;
+}
+
+extern "C" int ifl_set_conv1_tail(int nsteps, int algo)
+{
+    int prev = conv1_tail()[0];
+    if (nsteps >= 0 && nsteps <= IFL_MAX_COND) conv1_tail()[0] = nsteps;
+    if (algo >= 0 && algo <= 2) conv1_tail()[1] = algo;
+    return prev;
+}
+
+extern "C" int ifl_set_conv1_algo_level(int level, int algo)
+{
+    int prev = conv1_algo(level);
+    if (algo >= 0 && algo <= 2) conv1_algo(level) = algo;
     return prev;
 }
 

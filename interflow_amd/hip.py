@@ -109,6 +109,10 @@ def lib():
     L.ifl_set_schedule.restype = c_int
     L.ifl_set_conv1_algo.argtypes = [c_int]
     L.ifl_set_conv1_algo.restype = c_int
+    L.ifl_set_conv1_algo_level.argtypes = [c_int, c_int]
+    L.ifl_set_conv1_algo_level.restype = c_int
+    L.ifl_set_conv1_tail.argtypes = [c_int, c_int]
+    L.ifl_set_conv1_tail.restype = c_int
     L.ifl_set_conv3_algo.argtypes = [c_int]
     L.ifl_set_conv3_algo.restype = c_int
     L.ifl_set_chain_fusion.argtypes = [c_int]
@@ -148,7 +152,7 @@ ADAM_CHUNK = 4096             # IFL_ADAM_CHUNK of the header
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
-           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_cond_prepare", "ifl_flow_pass",
+           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_set_conv1_algo_level", "ifl_set_conv1_tail", "ifl_cond_prepare", "ifl_flow_pass",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo", "ifl_set_chain_fusion",
            "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep",
@@ -164,6 +168,17 @@ def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -
 
 
 CONV1_DIRECT, CONV1_WINOGRAD, CONV1_WINOGRAD4 = 0, 1, 2
+
+
+def set_conv1_tail(nsteps: int = -1, algo: int = -1) -> int:
+    """ifl_set_conv1_tail: the last `nsteps` conditional steps of the last level by `algo` (default 4 by F(2x2)); returns the
+    previous number of steps."""
+    return int(lib().ifl_set_conv1_tail(nsteps, algo))
+
+
+def set_conv1_algo_level(level: int, algo: int = -1) -> int:
+    """ifl_set_conv1_algo_level: the bulk convolution's algorithm at one flow level (1 = first, 2 = deeper); returns the previous one."""
+    return int(lib().ifl_set_conv1_algo_level(level, algo))
 
 
 def set_conv1_algo(algo: int = -1) -> int:

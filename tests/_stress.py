@@ -73,3 +73,22 @@ def noise_aware_close(got, ref32, truth64, tol, what=""):
         assert e[i] <= allowed, (f"{what}: {name} rel err vs float64 {e[i]:.3e} > {allowed:.1e} "
                                  f"(tolerance {tol:.0e}, reference's own noise {n[i]:.2e})")
     return e, n
+
+
+ROUNDTRIP_K = 2.0
+
+
+def roundtrip_close(got, x, ref_roundtrip, tol, what=""):
+    """decode(encode(x)) against x.  float32 itself limits this quantity in the stress regime: the reference's own round trip
+    (stored in the fixture) is 4.3e-5 ... 7.4e-5 of |x|max away from x, and even a float64 decode of its float32 z is (7.2e-5 on
+    the third seed).  Accepted: within `tol`, or within ROUNDTRIP_K = 2 times the reference's own round-trip error, whichever is
+    larger, max-norm and element-wise.  Returns (ours, the reference's)."""
+    import torch
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    e, n = _errs(got, x), _errs(np.asarray(ref_roundtrip), x)
+    for i, name in enumerate(("max-norm", "element-wise")):
+        allowed = max(tol, ROUNDTRIP_K * n[i])
+        assert np.isfinite(e[i]) and e[i] <= allowed, (f"{what}: {name} round-trip error {e[i]:.3e} > {allowed:.1e} "
+                                                       f"(tolerance {tol:.0e}, the reference's own round trip {n[i]:.2e})")
+    return e, n

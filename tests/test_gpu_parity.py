@@ -10,7 +10,7 @@ import torch
 from interflow_amd import hip, synth
 from interflow_amd.flow_model import Gaussian, InterpFlow
 from oracle import interflow_oracle as O
-from tests._stress import elementwise_close, noise_aware_close, stress_fixture, stress_state
+from tests._stress import elementwise_close, noise_aware_close, roundtrip_close, stress_fixture, stress_state
 
 pytestmark = pytest.mark.gpu
 SCALES = [2, 4]
@@ -266,14 +266,38 @@ def test_chain_fusion_gives_the_same_bits(model):
         rel_close(xr, x.cpu().numpy(), what="round trip")
 
 
-@pytest.mark.parametrize("algo", [hip.CONV1_DIRECT, hip.CONV1_WINOGRAD, hip.CONV1_WINOGRAD4])
+class conv1_form:
+    """The bulk convolution's algorithm for a block of code: "default" = what the library ships (F(4x4,3x3) with the last 4
+    conditional steps of the last level by F(2x2,3x3): ifl_set_conv1_tail), or ONE pure form at every step (0 direct, 1 F(2x2),
+    2 F(4x4): the tail switched off)."""
+
+    def __init__(self, algo):
+        self.algo = algo
+
+    def __enter__(self):
+        self.prev = (hip.set_conv1_algo_level(1), hip.set_conv1_algo_level(2), hip.set_conv1_tail())
+        if self.algo == "default":
+            assert self.prev == (hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD4, 4), self.prev      # the shipped defaults
+        else:
+            hip.set_conv1_algo(self.algo)
+            hip.set_conv1_tail(0)
+            assert hip.set_conv1_algo(-1) == self.algo and hip.set_conv1_tail() == 0
+
+    def __exit__(self, *exc):
+        hip.set_conv1_algo_level(1, self.prev[0])
+        hip.set_conv1_algo_level(2, self.prev[1])
+        hip.set_conv1_tail(self.prev[2])
+
+
+CONV1_FORMS = ["default", hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD, hip.CONV1_DIRECT]
+
+
+@pytest.mark.parametrize("algo", CONV1_FORMS)
 def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
     """Both forms of the bulk convolution (direct implicit GEMM, Winograd F(2x2,3x3)) meet the tolerance against the
     reference's outputs on the 160x160 fixture, on an image whose deeper planes have odd sizes (20x36 -> 5x9: the
     Winograd tiles overhang the plane) and on a single conditional step with a 1x1 plane."""
-    prev = hip.set_conv1_algo(algo)
-    try:
-        assert hip.set_conv1_algo(-1) == algo
+    with conv1_form(algo):
         g = load(golden_dir, "full160_seed0.npz", sd_np)
         B, H = 2, 160
         x = t(synth.synth_images(1, B, H, H)).to(dev())
@@ -300,8 +324,6 @@ def test_conv1_algorithms_against_golden(golden_dir, sd_np, sd, model, algo):
             zw, lw = O.flow_step(zz, l0, False, ft, sd, f"flow_upsampler.layers.{li}.")
             out, ldo = step(zz.to(dev()), l0.to(dev()), reverse=False, rrdbResults=ft.to(dev()))
             rel_close(out, zw, what=f"step {li} {hw} z"); rel_close(ldo, lw, 2e-4, what=f"step {li} {hw} logdet")
-    finally:
-        hip.set_conv1_algo(prev)
 
 
 @pytest.mark.parametrize("algo", [hip.CONV3_DIRECT, hip.CONV3_WINOGRAD])
@@ -381,20 +403,19 @@ def _stress_inputs(g, B, H, xs, fs):
     return x, feats
 
 
-@pytest.mark.parametrize("algo", [hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD, hip.CONV1_DIRECT])
+@pytest.mark.parametrize("algo", CONV1_FORMS)
 def test_stress_goldens_all_conv1_algorithms(stress, algo):
     """Reference outputs for a second weight seed with coupling scales spanning ~0.15-0.999 and conditioning features of
     rms 2 (tests/golden/make_golden_stress.py), 32x32 and 160x160, batch 2, for every form of the bulk convolution.
       z, logdet (encode) and logdet (decode): against the reference at 1e-4, max-norm AND element-wise.
-      reconstructed x = decode(encode(x)) on the HIP path: against x at 1e-4 max-norm (the reference's own round trip is
-        4.9e-5 max-norm, 8.4e-5 element-wise on this fixture, so the element-wise bound is 2e-4).
+      reconstructed x = decode(encode(x)) on the HIP path: against x at 1e-4, or twice the reference's own round-trip error
+        (4.9e-5 max-norm, 8.4e-5 element-wise on this fixture), whichever is larger (tests/_stress.py:roundtrip_close).
       x decoded from the REFERENCE's z: internal activations reach |z| ~ 50 while x is in [0, 1], so an absolute error that is
         7e-6 of the flow's dynamic range is 3e-4 of |x|max; float32 itself is at its limit here (the reference's x_rec is 5e-5
         away from a float64 decode of the same z).  Held to the float64 decode with tests/_stress.py:noise_aware_close
         (1e-4, or NOISE_K = 4 x the reference's own float32 noise in that quantity; round 2 needed 8)."""
     g, model = stress
-    prev = hip.set_conv1_algo(algo)
-    try:
+    with conv1_form(algo):
         for tag, B, H, xs, fs in (("s32", 2, 32, 31, 32), ("s160", 2, 160, 33, 34)):
             x, feats = _stress_inputs(g, B, H, xs, fs)
             z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False, )
@@ -402,8 +423,7 @@ def test_stress_goldens_all_conv1_algorithms(stress, algo):
             el = elementwise_close(ld, g[f"{tag}_ld"], RTOL, f"{tag} logdet")
             noise_aware_close(z, g[f"{tag}_z"], g[f"{tag}_z64"], RTOL, f"{tag} z vs float64")
             xo, ldo = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
-            eo = _errs_pair(xo, x)
-            assert eo[0] <= RTOL and eo[1] <= 2 * RTOL, (tag, eo)
+            eo, _ = roundtrip_close(xo, x, g[f"{tag}_xr"], RTOL, f"{tag} decode(encode(x))")
             elementwise_close(-ldo, ld, RTOL, f"{tag} logdet cancels")
             xr, ldr = model(t(g[f"{tag}_z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
             ex, nx = noise_aware_close(xr, g[f"{tag}_xr"], g[f"{tag}_xr64"], RTOL, f"{tag} x decoded from the reference's z")
@@ -411,8 +431,6 @@ def test_stress_goldens_all_conv1_algorithms(stress, algo):
             print(f"stress {tag} algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  logdet {el[0]:.2e}  "
                   f"own round trip {eo[0]:.2e} {eo[1]:.2e}  x(ref z) vs float64 {ex[0]:.2e} {ex[1]:.2e} "
                   f"[reference's own {nx[0]:.2e} {nx[1]:.2e}; allowed {max(RTOL, 4 * nx[0]):.2e} {max(RTOL, 4 * nx[1]):.2e}]")
-    finally:
-        hip.set_conv1_algo(prev)
 
 
 def test_stress_third_seed(golden_dir):
@@ -424,23 +442,24 @@ def test_stress_third_seed(golden_dir):
     model = model.eval().to(dev())
     B, H, xs, fs = (int(v) for v in g["cases"][0])
     x, feats = _stress_inputs(g, B, H, xs, fs)
-    prev = hip.set_conv1_algo(-1)
-    try:
-        for algo in (hip.CONV1_WINOGRAD4, hip.CONV1_WINOGRAD, hip.CONV1_DIRECT):
-            hip.set_conv1_algo(algo)
+    for algo in ("default", hip.CONV1_WINOGRAD, hip.CONV1_DIRECT):
+        with conv1_form(algo):
             z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
             ez = elementwise_close(z, g["s160_z"], RTOL, "seed 2 z")
             elementwise_close(ld, g["s160_ld"], RTOL, "seed 2 logdet")
             xo, ldo = model(z, x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
-            eo = _errs_pair(xo, x)
-            assert eo[0] <= RTOL and eo[1] <= 2 * RTOL, eo
+            eo, no = roundtrip_close(xo, x, g["s160_xr"], RTOL, "seed 2 decode(encode(x))")
             xr, ldr = model(t(g["s160_z"]).to(dev()), x, reverse=True, lr_enc=feats, add_gt_noise=False, test_input_size=H)
             ex, nx = noise_aware_close(xr, g["s160_xr"], g["s160_xr64"], RTOL, "seed 2 x decoded from the reference's z")
             elementwise_close(ldr, g["s160_ldr"], RTOL, "seed 2 logdet rev")
-            print(f"stress seed 2 s160 algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  own round trip {eo[0]:.2e} {eo[1]:.2e}  "
+            print(f"stress seed 2 s160 algo {algo} (max-norm, element-wise): z {ez[0]:.2e} {ez[1]:.2e}  own round trip {eo[0]:.2e} {eo[1]:.2e} [reference's {no[0]:.2e} {no[1]:.2e}]  "
                   f"x(ref z) vs float64 {ex[0]:.2e} {ex[1]:.2e} [reference's own {nx[0]:.2e} {nx[1]:.2e}; allowed {max(RTOL, 4 * nx[0]):.2e} {max(RTOL, 4 * nx[1]):.2e}]")
-    finally:
-        hip.set_conv1_algo(prev)
+    # F(4x4) at EVERY step is the one form outside 4x the reference's noise on this seed (4.6x element-wise, profiles/r03_notes.md):
+    # the reason for the shipped tail of four F(2x2) steps; it still meets the plain criteria on z and logdet
+    with conv1_form(hip.CONV1_WINOGRAD4):
+        z, ld = model(x, None, lr_enc=feats, add_gt_noise=False, calc_loss=False)
+        elementwise_close(z, g["s160_z"], RTOL, "seed 2 z, F(4x4) at every step")
+        elementwise_close(ld, g["s160_ld"], RTOL, "seed 2 logdet, F(4x4) at every step")
 
 
 def _errs_pair(got, want):
