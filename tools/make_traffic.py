@@ -40,7 +40,8 @@ def main():
                     "XCD works on both networks of one step for half of the tile groups (the two workgroups of a group share "
                     "its images in the XCD's L2), so each of the 8 XCDs fetches half of the images: 4 x 590 MB over the fabric "
                     "(8 x with one pair per XCD, the mapping before r02g); the XCDs walk the groups in step, so all but the first "
-                    "read of a line hit the Infinity Cache, which FETCH_SIZE counts."}
+                    "read of a line hit the Infinity Cache, which FETCH_SIZE counts.  Round 3: conv1_ft_wino4_kernel<2> runs 6 steps per "
+                    "launch, conv1_ft_wino_kernel<2> is the F(2x2,3x3) form of the last 4 conditional steps (ifl_set_conv1_tail)."}
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps({k: v["bytes_per_launch"] for k, v in res.items()}))
 
