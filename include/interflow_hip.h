@@ -218,7 +218,9 @@ int ifl_gaussian_logp(const float* z, const float* mean, const float* cov_inv, f
  * allocates and frees nothing.  Limit: B * ifl_logp_scratch_floats(H*W) <= IFL_LOGP_STATIC_MAX_FLOATS, otherwise
  * IFL_ENOTSUP (use ifl_gaussian_logp).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
  * streams, two host threads) race; calls on one stream, or otherwise ordered, are safe (each call overwrites every slot it
- * later reads, so nothing carries over from the call before).                                                       */
+ * later reads, so nothing carries over from the call before).  The FIRST call on a device looks the array's address up
+ * (hipGetSymbolAddress, which may load the code object): make one warm-up call per device outside graph capture.
+ * Alignment: z 4 bytes (16 selects the vector form), mean and cov_inv 4 bytes.                                        */
 #define IFL_LOGP_STATIC_MAX_FLOATS 65536
 int ifl_gaussian_logp_static(const float* z, const float* mean, const float* cov_inv, float logdet_cov, float* out,
                              int B, int C, int H, int W, void* stream);

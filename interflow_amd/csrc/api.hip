@@ -939,6 +939,13 @@ extern "C" int ifl_resize_sep(const float* x, float* out, int N, int Hin, int Wi
     IFL_CHECK_ARG(N >= 0 && N <= 65535 && Hin >= 1 && Win >= 1 && Hout >= 0 && Wout >= 0, IFL_EINVAL, "bad shape");
     IFL_CHECK_ARG(TH >= 1 && TW >= 1 && TH <= 64 && TW <= 64, IFL_EINVAL, "taps %d, %d outside 1..64", TH, TW);
     IFL_CHECK_ARG(Win <= 8192, IFL_ENOTSUP, "input rows of %d values exceed the LDS row buffer", Win);
+    {   // the kernel asks for 4 rows x Win floats of dynamic LDS: 128 KiB at the limit, inside gfx950's 160 KiB per workgroup
+        int dev = 0, lds = 0;
+        IFL_HIP(hipGetDevice(&dev));
+        IFL_HIP(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        IFL_CHECK_ARG(16 * (int64_t)Win <= lds, IFL_ENOTSUP, "input rows of %d values need %lld bytes of LDS, the device has %d per workgroup",
+                      Win, (long long)(16 * (int64_t)Win), lds);
+    }
     return ifl_k_resize_sep(x, out, N, Hin, Win, Hout, Wout, idxH, wH, TH, idxW, wW, TW, (hipStream_t)stream);
 }
 

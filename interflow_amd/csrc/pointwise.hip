@@ -244,7 +244,8 @@ void logp48_mfma_kernel(const float* __restrict__ z, const float* __restrict__ m
     f32x4 a[3][3], mu[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        mu[j] = *(const f32x4*)(mean + 16 * j + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mu[j][e] = mean[16 * j + 4 * g + e];      // (element loads: the header promises no alignment for mean)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll

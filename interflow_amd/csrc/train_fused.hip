@@ -586,10 +586,15 @@ int train_fork(TrainFork** out)
     IFL_HIP(hipGetDevice(&dev));
     IFL_CHECK_ARG(dev >= 0 && dev < IFL_MAX_DEVICES, IFL_ENOTSUP, "device %d", dev);
     TrainFork& f = g_tfork[dev];
-    if (!f.aux) {
-        IFL_HIP(hipStreamCreateWithFlags(&f.aux, hipStreamNonBlocking));
-        IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
-        IFL_HIP(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> once(f.mu);          // two host threads making their first call on one device
+        if (!f.aux) {
+            hipStream_t aux = nullptr;
+            IFL_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+            IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+            IFL_HIP(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+            f.aux = aux;                                  // last: marks the context as complete
+        }
     }
     *out = &f;
     return 0;

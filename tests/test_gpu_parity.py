@@ -611,6 +611,44 @@ def test_gaussian_prior_and_loss(golden_dir, sd_np, sd, model):
         rel_close(got, O.gaussian_logp(mu, cov, zz), what=f"full C={C}")
 
 
+def test_loss_evaluation_reads_nothing_back_from_the_device(golden_dir, sd_np, model):
+    """flow.py:146-149 inverts the class covariance on every Gaussian.logp call (here that was a copy to the host and a host
+    inverse per class and call).  The inverses and log-determinants are now cached on the device per parameter version, the
+    labels go up through pinned memory, and the selected log-softmax entries are gathered with host-made indices: in steady
+    state calculate_loss, loss_terms and get_pdf run without a single host/device synchronisation (torch's sync debug mode
+    raises on one), with the values of the synchronising path; an updated covariance is picked up."""
+    g = load(golden_dir, "ops_seed0.npz", sd_np)
+    z = t(g["g_z"]).to(dev())
+    ld = t(g["loss_ld"]).to(dev())
+    label = t(g["loss_label"])                                   # on the host, as train.py:69 builds it
+    want = model.calculate_loss(z, ld, 20 * 24, label.to(dev()))   # device labels: the masked_select path (synchronises)
+    model.get_pdf(z, [2, 4])
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        got = model.calculate_loss(z, ld, 20 * 24, label)
+        nll2, ib2 = model.loss_terms(z, ld, 20 * 24, label)
+        pdf = model.get_pdf(z, [2, 4])
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
+    rel_close(got[1], g["loss_nll"], what="nll"); rel_close(got[3], g["loss_ll_ib"], 1e-3, what="ll_ib")
+    rel_close(nll2, g["loss_nll"], what="nll (loss_terms)"); rel_close(pdf, g["pdf"], what="get_pdf")
+    assert abs(float(ib2) + float(want[3].mean())) <= 1e-5 * abs(float(ib2))
+    # a new parameter version is seen (the cache is keyed on it)
+    with torch.no_grad():
+        model.cov_shift_1.mul_(1.5)
+    try:
+        changed = model.calculate_loss(z, ld, 20 * 24, label)
+        cov = model.cov_shift_1 @ model.cov_shift_1.T
+        mean = model.mean_shift_1 * torch.ones(48, device=dev())
+        rel_close(hip.gaussian_logp(z, *model._prior(1, z.device)), O.gaussian_logp(mean.cpu(), cov.cpu(), z.cpu()), what="updated prior")
+        assert not torch.equal(changed[1], want[1])
+    finally:
+        with torch.no_grad():
+            model.cov_shift_1.div_(1.5)
+
+
 def test_lerp():
     gen = torch.Generator().manual_seed(3)
     z1, z2 = torch.randn(4, 48, 40, 40, generator=gen), torch.randn(4, 48, 40, 40, generator=gen)
