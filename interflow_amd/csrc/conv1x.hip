@@ -122,9 +122,12 @@ __device__ __forceinline__ void at_part(int blk, const f32x16& m0, const f32x16&
 // Build with -DIFL_EXP_TIME (tools/build_exp.sh) to record per-wave timestamps (tools/exp_x4_timeline.py); never defined in
 // the product build.
 #ifdef IFL_EXP_TIME
+#ifndef IFL_EXP_TIME_LVL
+#define IFL_EXP_TIME_LVL 1
+#endif
 __device__ unsigned long long ifl_dbgx[8192 * 8 * 8];
-#define XT_STAMP(k) do { if (LVL == 1 && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
-#define XT_PUT(k, v) do { if (LVL == 1 && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = (v); } while (0)
+#define XT_STAMP(k) do { if (LVL == IFL_EXP_TIME_LVL && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
+#define XT_PUT(k, v) do { if (LVL == IFL_EXP_TIME_LVL && lane == 0 && blockIdx.x < 8192) ifl_dbgx[(blockIdx.x * 8 + wave) * 8 + (k)] = (v); } while (0)
 #define XT_CLK() clock64()
 #else
 #define XT_STAMP(k) do {} while (0)

@@ -27,7 +27,9 @@ L.ifl_dbgx_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = L.ifl_dbgx_read(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 t = buf.reshape(nwg, 8, 8).astype(np.int64)
-nwg = min(nwg, 32 * ((B * 400 + 31) // 32))        # level-1 workgroups of ifl_cond_prepare: 32 (network, step) pairs x groups
+LVL = int(os.environ.get("EXP_LVL", "1"))           # the library must be built with -DIFL_EXP_TIME_LVL=2 for level 2
+tiles = B * (400 if LVL == 1 else 100)
+nwg = min(nwg, 32 * ((tiles + 31) // 32))          # workgroups of one launch of ifl_cond_prepare at that level: 32 (network, step) pairs x groups
 t = t[:nwg]
 ns = lambda a: a * 10.0          # 100 MHz ticks -> ns
 net = (np.arange(nwg) & 1)       # combo = (id & 7) + ...: net = combo & 1 = id & 1 when ncombo % 8 == 0
