@@ -80,6 +80,9 @@ def main():
                     help="skip the secondary fields measured AFTER the timed region by default: `cond_reuse` (encode + decode with "
                          "one shared conditioning preparation), `serial_schedule` (the steps on one stream: the dominant kernel "
                          "alone) and `kernels_ms_per_step` (every kernel of one step timed)")
+    ap.add_argument("--no-cross-pass-overlap", action="store_true",
+                    help="every pass's bulk convolutions behind the whole previous pass (the plain stream order) instead of behind "
+                         "its bulk convolutions only (hip.set_cross_pass_overlap: passes in a row on unchanged conditioning tensors)")
     ap.add_argument("--breakdown", action="store_true", help="(kept for old command lines: the breakdown is on by default)")
     args = ap.parse_args()
 
@@ -90,6 +93,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     dev, backend = shard.rank_device()             # cuda:LOCAL_RANK, RCCL
     torch.cuda.set_device(dev)
+    if args.no_cross_pass_overlap:
+        hip.set_cross_pass_overlap(False)
     dist = shard.init_dist(backend, dev)            # RCCL; only the barrier and the max-over-ranks clock use it
 
     sd_np = synth.synth_interpflow_state(SCALES, seed=0)
@@ -236,6 +241,7 @@ def main():
             "config": {"workload": f"InterFlow flow encode+decode, batch {B} of 160x160 RGB patches per GPU, fp32, "
                                    "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
                                    "add_gt_noise=False (BASELINE.json configs[1])",
+                       "cross_pass_overlap": bool(hip.set_cross_pass_overlap()),
                        "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)",
                        "world_size": dist.get_world_size() if dist is not None else 1, "ranks": ranks},
             "roofline": {"bound": "mfma",

@@ -136,6 +136,23 @@ int ifl_flow_decode(const ifl_layer* layers, int n_layers, const float* params, 
  * tests/test_gpu_parity.py).                                                                                              */
 #define IFL_FLOW_BF16_CONV1 2
 #define IFL_FLOW_BF16_CHAIN 4
+/* IFL_FLOW_COND_EARLY + ifl_load_cond_early: passes that follow each other on UNCHANGED conditioning features (no counterpart in
+ * the reference, whose passes are ordinary stream-ordered module calls).  A pass's bulk convolutions read the features and the
+ * weights only, yet the caller's stream orders them behind the whole previous pass, so the chip runs the tail of that pass's
+ * per-step chain (about a tenth of a pass) without them.  ifl_load_cond_early is ifl_load_cond enqueued on the library's bulk
+ * stream, behind what that stream already holds and behind `after_event` (a hipEvent_t, or NULL), instead of on a stream of the
+ * caller; ifl_flow_pass with IFL_FLOW_COND_EARLY then starts its bulk work behind those loads without waiting for the calling
+ * stream (the chain still runs on the calling stream, behind everything it holds).  The caller promises that
+ *   - `ft_nchw` was complete, on the stream the previous pass (ifl_flow_pass / encode / decode) on this device was issued to,
+ *     when that pass was issued -- e.g. that pass loaded the same buffer -- and nothing has written it since (the loads wait
+ *     for that point of that stream): the library cannot see who produces the features, which is why this is a flag;
+ *   - `after_event` covers the last work that used `ws` (pass, ifl_cond_prepare, ifl_flow_step): the loads overwrite its
+ *     conditioning and the bulk work its slabs.  In practice: two workspaces used in turn, an event recorded behind each pass;
+ *   - both levels are loaded with ifl_load_cond_early before the pass, and the pass is the next library call that uses `ws`.
+ * Results are identical, bit for bit, to the ordinary order.  With the one-stream schedule (ifl_set_schedule aux_stream = 0)
+ * the pass waits for the early loads and nothing overlaps.                                                                */
+#define IFL_FLOW_COND_EARLY 8
+int ifl_load_cond_early(void* ws, int B, int H, int W, int level, const float* ft_nchw, void* after_event);
 int ifl_cond_prepare(const ifl_layer* layers, int n_layers, const float* params, void* ws, int B, int H, int W,
                      float eps, int flags, void* stream);
 int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, void* ws, const float* src, float* dst,

@@ -402,7 +402,7 @@ struct ForkCtx {
                          // streams on one device are correct as long as their enqueue sequences do not interleave
     bool ok = false;
     hipStream_t aux, s[IFL_MAX_GROUPS - 1];
-    hipEvent_t fork, aux_done, join[IFL_MAX_GROUPS - 1], p1[MAX_P1_EVENTS];
+    hipEvent_t fork, aux_done, early, join[IFL_MAX_GROUPS - 1], p1[MAX_P1_EVENTS];
 };
 ForkCtx g_fork[IFL_MAX_DEVICES];
 
@@ -427,6 +427,7 @@ int fork_ctx(ForkCtx** out, std::unique_lock<std::mutex>* lock)
         for (int i = 0; i < MAX_P1_EVENTS; ++i) IFL_HIP(hipEventCreateWithFlags(&f.p1[i], hipEventDisableTiming));
         IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
         IFL_HIP(hipEventCreateWithFlags(&f.aux_done, hipEventDisableTiming));
+        IFL_HIP(hipEventCreateWithFlags(&f.early, hipEventDisableTiming));
         f.ok = true;
     }
     *out = &f;
@@ -651,9 +652,11 @@ int chain_group(bool decode, const ifl_layer* layers, int n_layers, const float*
                              w.lv[0].ld_f0, plan.n[0] * f_slots(w.lv[0], bf16 & 1), w.lv[1].ld_f0, plan.n[1] * f_slots(w.lv[1], bf16 & 1), B, st);
 }
 
+// early: the conditioning was put into `ws` by ifl_load_cond_early (bulk stream); the bulk work then follows it there without
+// waiting for the caller's stream -- it reads nothing that the caller's stream produces
 int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int n_layers, const float* params, void* ws,
              const float* src, float* dst, const float* logdet_in, float* logdet_out, int B, int H, int W, float eps,
-             hipStream_t st)
+             hipStream_t st, bool early = false)
 {
     IflWs w;
     ifl_ws_layout(ws, B, H, W, &w);
@@ -667,13 +670,14 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
     ForkCtx* f = nullptr;
     std::unique_lock<std::mutex> fork_lock;
     hipEvent_t* ev = nullptr;
-    if (use_aux || G > 1) {
-        if ((rc = fork_ctx(&f, &fork_lock))) return rc;
-        IFL_HIP(hipEventRecord(f->fork, st));
-    }
+    // (every pass records f->fork at its entry: ifl_load_cond_early orders the bulk stream behind the previous pass's entry)
+    if ((rc = fork_ctx(&f, &fork_lock))) return rc;
+    IFL_HIP(hipEventRecord(f->fork, st));
     if (use_aux) {
         ev = f->p1;
-        IFL_HIP(hipStreamWaitEvent(f->aux, f->fork, 0));
+        if (!early) IFL_HIP(hipStreamWaitEvent(f->aux, f->fork, 0));
+    } else if (early) {
+        IFL_HIP(hipStreamWaitEvent(st, f->early, 0));             // one-stream schedule: behind the early load, no overlap
     }
     hipStream_t p1s = use_aux ? f->aux : st;
     // phase 1 in the order the chain consumes the levels
@@ -796,11 +800,32 @@ extern "C" int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float*
     if (rc) return rc;
     if ((rc = check_layers(layers, n_layers))) return rc;
     IFL_CHECK_ARG(params && ws && src && dst && logdet_out, IFL_EINVAL, "null pointer");
-    IFL_CHECK_ARG((flags & ~(IFL_FLOW_COND_PREPARED | IFL_FLOW_BF16_CONV1 | IFL_FLOW_BF16_CHAIN)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
+    IFL_CHECK_ARG((flags & ~(IFL_FLOW_COND_PREPARED | IFL_FLOW_BF16_CONV1 | IFL_FLOW_BF16_CHAIN | IFL_FLOW_COND_EARLY)) == 0, IFL_EINVAL, "unknown flags 0x%x", flags);
     IFL_CHECK_ARG(!(flags & IFL_FLOW_BF16_CHAIN) || (flags & IFL_FLOW_BF16_CONV1), IFL_EINVAL, "IFL_FLOW_BF16_CHAIN needs IFL_FLOW_BF16_CONV1");
+    IFL_CHECK_ARG(!(flags & IFL_FLOW_COND_EARLY) || !(flags & IFL_FLOW_COND_PREPARED), IFL_EINVAL, "IFL_FLOW_COND_EARLY with IFL_FLOW_COND_PREPARED: nothing left to start early");
     // bf16 mask inside the drivers: bit 0 = the z-independent convolutions (bulk phase), bit 1 = fAffine's z-dependent ones (chain)
     return run_flow(decode != 0, (flags & IFL_FLOW_COND_PREPARED) != 0, ((flags & IFL_FLOW_BF16_CONV1) ? 1 : 0) | ((flags & IFL_FLOW_BF16_CHAIN) ? 2 : 0), layers, n_layers, params, ws, src, dst, logdet_in,
-                    logdet_out, B, H, W, eps, (hipStream_t)stream);
+                    logdet_out, B, H, W, eps, (hipStream_t)stream, (flags & IFL_FLOW_COND_EARLY) != 0);
+}
+
+extern "C" int ifl_load_cond_early(void* ws, int B, int H, int W, int level, const float* ft_nchw, void* after_event)
+{
+    int rc = check_shape(B, H, W);
+    if (rc) return rc;
+    IFL_CHECK_ARG(ws && ft_nchw, IFL_EINVAL, "null pointer");
+    IFL_CHECK_ARG(level >= 1 && level <= IFL_MAX_LEVELS, IFL_EINVAL, "level %d outside 1..%d", level, IFL_MAX_LEVELS);
+    IflWs w;
+    ifl_ws_layout(ws, B, H, W, &w);
+    ForkCtx* f = nullptr;
+    std::unique_lock<std::mutex> fork_lock;
+    if ((rc = fork_ctx(&f, &fork_lock))) return rc;
+    // behind the entry of the previous pass on its calling stream (where, by the caller's promise, the features were complete)
+    // -- the bulk stream is already there unless that pass ran on the one-stream schedule -- and behind `after_event`
+    IFL_HIP(hipStreamWaitEvent(f->aux, f->fork, 0));
+    if (after_event) IFL_HIP(hipStreamWaitEvent(f->aux, (hipEvent_t)after_event, 0));
+    if ((rc = load_ft(w.lv[level - 1], B, ft_nchw, f->aux))) return rc;
+    IFL_HIP(hipEventRecord(f->early, f->aux));
+    return 0;
 }
 
 extern "C" int ifl_flow_step(const ifl_layer* layer, const float* params, void* ws, const float* z_in, float* z_out,

@@ -14,6 +14,7 @@ into those kernels and have no forward of their own here.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -203,6 +204,7 @@ class FlowStep(nn.Module):
             hip.check(hip.lib().ifl_flow_step(layers, hip._ptr(params), ws.ptr, hip._ptr(z), hip._ptr(out),
                                               hip._ptr(ft), hip._ptr(ld_in), hip._ptr(ld_out), B, h, w,
                                               1 if reverse else 0, eps, hip._stream()), "ifl_flow_step")
+            ws.mark_used()
         return out, (ld_out if logdet is not None else None)
 
 
@@ -292,6 +294,15 @@ def _as_logdet(logdet, B, device):
     return torch.full((B,), float(logdet), dtype=torch.float32, device=device)
 
 
+def _tensor_version(t):
+    """torch's in-place write counter of a tensor, or None for tensors that keep none (made under torch.inference_mode):
+    writes to those cannot be seen, so they never count as unchanged."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 class PreparedCond(dict):
     """`rrdbResults` whose conditioning-only part of every coupling network is already in a workspace
     (`FlowUpsamplerNet.prepare_cond`, `ifl_cond_prepare`).  Behaves as the plain dict everywhere; `FlowUpsamplerNet`
@@ -378,6 +389,7 @@ class FlowUpsamplerNet(nn.Module):
         self.H, self.W = H, W
         self.scaleH, self.scaleW = 160 / H, 160 / W
         self._packed = None
+        self._last_cond, self._pass_no = None, 0      # conditioning tensors of the previous pass (weak), passes so far
         self.affine_eps = opt_get(opt, ['network_G', 'flow', 'CondAffineSeparatedAndCond', 'eps'], 0.0001)
         # "fp32" (reference arithmetic); "bf16": the coupling networks' convolutions that depend only on the conditioning (95 % of
         # the FLOPs) on the bf16 matrix cores, operands rounded to bf16, fp32 accumulate -- encode and decode still invert each
@@ -447,13 +459,34 @@ class FlowUpsamplerNet(nn.Module):
         return self.encode(gt, rrdbResults, logdet=logdet, epses=epses, y_onehot=y_onehot,
                            test_input_size=test_input_size)
 
-    def _load_cond(self, ws, feats, B, H, W):
+    def _load_cond(self, ws, feats, B, H, W, early=False):
         L = hip.lib()
         ws.generation += 1
         for lv, ft in feats.items():
             ft = hip._dev_f32(ft, f"rrdbResults level {lv}")
             assert ft.shape == (B, N_RRDB_CH, H >> lv, W >> lv), (tuple(ft.shape), (B, N_RRDB_CH, H >> lv, W >> lv))
-            hip.check(L.ifl_load_cond(ws.ptr, B, H, W, lv, hip._ptr(ft), hip._stream()), "ifl_load_cond")
+            if early:
+                hip.check(L.ifl_load_cond_early(ws.ptr, B, H, W, lv, hip._ptr(ft), ws.done_handle()), "ifl_load_cond_early")
+            else:
+                hip.check(L.ifl_load_cond(ws.ptr, B, H, W, lv, hip._ptr(ft), hip._stream()), "ifl_load_cond")
+
+    # ---- passes in a row on unchanged conditioning tensors (hip.set_cross_pass_overlap) ----
+    def _cond_unchanged(self, feats):
+        """True when every conditioning tensor of this pass is the very tensor object the previous pass loaded, unwritten since
+        (torch's version counter) and usable as it is: the features were then complete before that pass was issued, which is
+        what IFL_FLOW_COND_EARLY asks the caller to know."""
+        last = self._last_cond
+        if last is None or set(last) != set(feats):
+            return False
+        for lv, ft in feats.items():
+            ref, version, ptr = last[lv]
+            if (version is None or ref() is not ft or _tensor_version(ft) != version or ft.data_ptr() != ptr
+                    or ft.dtype != torch.float32 or not ft.is_contiguous()):
+                return False
+        return True
+
+    def _remember_cond(self, feats):
+        self._last_cond = {lv: (weakref.ref(ft), _tensor_version(ft), ft.data_ptr()) for lv, ft in feats.items()}
 
     def prepare_cond(self, rrdbResults, batch, H, W, test_input_size=None):
         """Compute, once, the part of every coupling network that depends only on the conditioning features (the first
@@ -474,6 +507,7 @@ class FlowUpsamplerNet(nn.Module):
             self._load_cond(ws, enc, batch, H, W)
             hip.check(hip.lib().ifl_cond_prepare(layers, len(layers), hip._ptr(params), ws.ptr, batch, H, W,
                                                  float(self.affine_eps), self._flags(), hip._stream()), "ifl_cond_prepare")
+            ws.mark_used()
         return PreparedCond(rrdbResults, ws, ws.generation, (self._packed[0], self.conv_dtype), enc, (batch, H, W))
 
     def _needs_autograd(self, src, rrdbResults):
@@ -517,18 +551,31 @@ class FlowUpsamplerNet(nn.Module):
             out = torch.empty(B, self.C, H // 4, W // 4, dtype=torch.float32, device=src.device)
         feats = self._level_features(rrdbResults, H, test_input_size, decode)
         params, layers = self._pack(src.device)
-        ws = hip.Workspace.get(B, H, W, src.device)
         L = hip.lib()
         ld_in = _as_logdet(logdet, B, src.device)
         ld_out = torch.empty(B, dtype=torch.float32, device=src.device)
-        prepared = isinstance(rrdbResults, PreparedCond) and rrdbResults.usable(ws, (self._packed[0], self.conv_dtype), feats, (B, H, W))
         with torch.cuda.device(src.device):
-            if not prepared:
-                self._load_cond(ws, feats, B, H, W)
+            ws, prepared = None, False
+            if isinstance(rrdbResults, PreparedCond):
+                ws = hip.Workspace.get(B, H, W, src.device)           # where prepare_cond put it
+                prepared = rrdbResults.usable(ws, (self._packed[0], self.conv_dtype), feats, (B, H, W))
+            flags = self._flags()
+            if prepared:
+                flags |= hip.FLOW_COND_PREPARED
+            else:
+                # two workspaces in turn: the next pass may fill one while this pass's chain still reads the other
+                overlap = hip.set_cross_pass_overlap() and not torch.cuda.is_current_stream_capturing()
+                self._pass_no += 1
+                ws = hip.Workspace.get(B, H, W, src.device, slot=self._pass_no & 1 if overlap else 0)
+                early = overlap and self._cond_unchanged(feats)
+                self._load_cond(ws, feats, B, H, W, early=early)
+                self._remember_cond(feats)
+                if early:
+                    flags |= hip.FLOW_COND_EARLY
             hip.check(L.ifl_flow_pass(layers, len(layers), hip._ptr(params), ws.ptr, hip._ptr(src), hip._ptr(out),
                                       hip._ptr(ld_in), hip._ptr(ld_out), B, H, W, float(self.affine_eps),
-                                      1 if decode else 0, (hip.FLOW_COND_PREPARED if prepared else 0) | self._flags(), hip._stream()),
-                      "ifl_flow_pass")
+                                      1 if decode else 0, flags, hip._stream()), "ifl_flow_pass")
+            ws.mark_used()
         return out, ld_out
 
     def encode(self, gt, rrdbResults, logdet=0.0, epses=None, y_onehot=None, test_input_size=None):

@@ -19,6 +19,7 @@ IFL_EINVAL, IFL_ENOTSUP, IFL_ESMALLWS = -1, -2, -3
 FLOW_COND_PREPARED = 1
 FLOW_BF16_CONV1 = 2
 FLOW_BF16_CHAIN = 4
+FLOW_COND_EARLY = 8
 
 # field ids of the packed per-step parameter block (interflow_hip.h IFL_F_*)
 (F_ANIC_FWD, F_ANIC_INV, F_W1A, F_W1F, F_AN1A, F_AN1F, F_W2A, F_W2F, F_AN2A, F_AN2F,
@@ -66,6 +67,8 @@ def lib():
     L.ifl_ws_bytes.argtypes = [c_int, c_int, c_int]
     L.ifl_ws_init.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p]
     L.ifl_load_cond.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.ifl_load_cond_early.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.ifl_load_cond_early.restype = c_int
     flow_args = [POINTER(IflLayer), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                  c_int, c_int, c_int, c_float, c_void_p]
     L.ifl_flow_encode.argtypes = flow_args
@@ -152,7 +155,7 @@ ADAM_CHUNK = 4096             # IFL_ADAM_CHUNK of the header
 EXPORTS = ("ifl_version", "ifl_last_error", "ifl_step_param_floats", "ifl_step_field_off", "ifl_ws_bytes",
            "ifl_ws_init", "ifl_load_cond", "ifl_flow_encode", "ifl_flow_decode", "ifl_flow_step",
            "ifl_squeeze2d", "ifl_unsqueeze2d", "ifl_logp_scratch_floats", "ifl_gaussian_logp", "ifl_lerp",
-           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_set_conv1_algo_level", "ifl_set_conv1_tail", "ifl_cond_prepare", "ifl_flow_pass",
+           "ifl_prof_enable", "ifl_prof_read", "ifl_set_schedule", "ifl_set_conv1_algo", "ifl_set_conv1_algo_level", "ifl_set_conv1_tail", "ifl_cond_prepare", "ifl_flow_pass", "ifl_load_cond_early",
            "ifl_quantize_u8_nhwc", "ifl_rrdb_conv_count", "ifl_rrdb_param_floats", "ifl_rrdb_conv_desc", "ifl_rrdb_ws_bytes",
            "ifl_rrdb_ws_init", "ifl_rrdb_encode", "ifl_conv2d", "ifl_conv2d_wgrad", "ifl_gaussian_logp_static", "ifl_set_conv3_algo", "ifl_set_chain_fusion",
            "ifl_an_relu_blocks", "ifl_an_relu_fwd", "ifl_an_relu_bwd", "ifl_coupling_blocks", "ifl_coupling_fwd", "ifl_coupling_bwd", "ifl_resize_sep",
@@ -165,6 +168,22 @@ K_CONV1_FT_L1, K_CONV1_FT_L2, K_CONV1_FINISH, K_CONV3_F, K_CONV3_ENC, K_CONV3_DE
 def set_schedule(aux_stream: int = -1, groups: int = -1, p1_chunk_steps: int = -1):
     """Stream plan of the flow drivers (see ifl_set_schedule in interflow_hip.h); -1 keeps a setting."""
     check(lib().ifl_set_schedule(aux_stream, groups, p1_chunk_steps), "ifl_set_schedule")
+
+
+_cross_pass = [os.environ.get("IFL_CROSS_PASS_OVERLAP", "1") != "0"]
+
+
+def set_cross_pass_overlap(on=None) -> bool:
+    """Passes of FlowUpsamplerNet that follow each other on the SAME conditioning tensors (same objects, not written in
+    between: torch's version counters) start their bulk convolutions behind the previous pass's bulk convolutions instead of
+    behind its whole per-step chain (IFL_FLOW_COND_EARLY in interflow_hip.h; two workspaces per shape used in turn).  Default
+    on (environment IFL_CROSS_PASS_OVERLAP=0: off); `None` only queries.  Results are bit-identical either way.  Turn it off
+    if conditioning tensors are written behind torch's back (a kernel of your own on `.data_ptr()`): the version counter is
+    all this layer can see.  Returns the previous setting."""
+    prev = _cross_pass[0]
+    if on is not None:
+        _cross_pass[0] = bool(on)
+    return prev
 
 
 CONV1_DIRECT, CONV1_WINOGRAD, CONV1_WINOGRAD4 = 0, 1, 2
@@ -260,21 +279,33 @@ class Workspace:
         self.B, self.H, self.W = B, H, W
         self.nbytes = nbytes
         self.generation = 0          # bumped whenever the conditioning maps / slabs in this workspace are overwritten
+        self.done = None             # event behind the last work enqueued on this workspace (mark_used)
         with torch.cuda.device(device):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.ifl_ws_init(_ptr(self.buf), nbytes, B, H, W, _stream()), "ifl_ws_init")
+            self.mark_used()         # the initialisation is the first work on it (an early load must not overtake it)
 
     @property
     def ptr(self):
         return _ptr(self.buf)
 
+    def mark_used(self):
+        """Record, on the current stream, the end of the work just enqueued on this workspace: what an early conditioning load
+        of a later pass (ifl_load_cond_early) waits for before it overwrites the workspace from the library's bulk stream."""
+        if self.done is None:
+            self.done = torch.cuda.Event()
+        self.done.record()
+
+    def done_handle(self):
+        return c_void_p(self.done.cuda_event) if self.done is not None else c_void_p(0)
+
     @classmethod
-    def get(cls, B, H, W, device):
+    def get(cls, B, H, W, device, slot=0):
         key = (B, H, W, torch.device(device).index if torch.device(device).index is not None
-               else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+               else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, slot)
         ws = cls._cache.get(key)
         if ws is None:
-            if len(cls._cache) >= 4:          # a few live shapes at most; drop the oldest
+            if len(cls._cache) >= 8:          # a few live shapes (two workspaces each) at most; drop the oldest
                 cls._cache.pop(next(iter(cls._cache)))
             ws = cls(B, H, W, device)
             cls._cache[key] = ws

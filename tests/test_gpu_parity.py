@@ -690,7 +690,8 @@ def test_prepared_cond_is_bit_identical(model):
         a, b = fu(z=z1, rrdbResults=prep, logdet=ld0, reverse=True)
         assert torch.equal(a, xr) and torch.equal(b, lr)
     assert prep._ws.generation == gen, "prepared passes must not reload the conditioning"
-    zo, _ = fu(gt=x1, rrdbResults=other, logdet=ld0, reverse=False)          # overwrites the workspace's slabs
+    for _ in range(2):            # (plain passes take the shape's two workspaces in turn: one of these is the prepared one)
+        zo, _ = fu(gt=x1, rrdbResults=other, logdet=ld0, reverse=False)      # overwrites the workspace's slabs
     assert not torch.equal(zo, z1) and prep._ws.generation != gen
     a, b = fu(gt=x1, rrdbResults=prep, logdet=ld0, reverse=False)            # stale preparation: ordinary path
     assert torch.equal(a, z1) and torch.equal(b, l1)
@@ -700,6 +701,91 @@ def test_prepared_cond_is_bit_identical(model):
         fu.layers[3].actnorm.bias.add_(0.0)                                   # bumps the version counter only
     a, b = fu(gt=x1, rrdbResults=prep, logdet=ld0, reverse=False)
     assert torch.equal(a, z1) and torch.equal(b, l1)
+
+
+def test_passes_in_a_row_on_unchanged_conditioning_start_early_and_give_the_same_bits(model, monkeypatch):
+    """hip.set_cross_pass_overlap (IFL_FLOW_COND_EARLY / ifl_load_cond_early): a pass whose conditioning tensors are the very
+    objects of the previous pass, unwritten since, loads them and starts its bulk convolutions on the library's bulk stream
+    behind the previous pass's bulk work.  Same kernels on the same data: bit-identical outputs.  A written tensor (version
+    counter), a new tensor object or a converted copy must take the ordinary order, and see the new values."""
+    B, H, W = 3, 32, 48
+    fu = model.flow_upsampler
+    x1, x2 = (t(synth.synth_images(s, B, H, W)).to(dev()) for s in (51, 52))
+    feats = {k: t(v).to(dev()) for k, v in synth.synth_features(53, B, H, W).items()}
+    ld0 = torch.zeros(B, device=dev())
+    L = hip.lib()
+    calls = {"early": 0, "plain": 0}
+    real_early, real_plain = L.ifl_load_cond_early, L.ifl_load_cond
+
+    def spy_early(*a):
+        calls["early"] += 1
+        return real_early(*a)
+
+    def spy_plain(*a):
+        calls["plain"] += 1
+        return real_plain(*a)
+    monkeypatch.setattr(L, "ifl_load_cond_early", spy_early)
+    monkeypatch.setattr(L, "ifl_load_cond", spy_plain)
+
+    def passes(f):
+        z1, l1 = fu(gt=x1, rrdbResults=f, logdet=ld0, reverse=False)
+        xr, lr = fu(z=z1, rrdbResults=f, logdet=ld0, reverse=True)
+        z2, l2 = fu(gt=x2, rrdbResults=f, logdet=ld0, reverse=False)
+        return [z1, l1, xr, lr, z2, l2]
+
+    prev = hip.set_cross_pass_overlap(False)
+    try:
+        want = passes(feats)
+        assert calls == {"early": 0, "plain": 6}
+        hip.set_cross_pass_overlap(True)
+        fu._last_cond = None
+        hip.Workspace.clear()            # fresh workspaces: their initialisation is enqueued on the calling stream,
+        calls.update(early=0, plain=0)   # the early load of the second pass must wait for it
+        got = passes(feats) + passes(feats)
+        assert calls == {"early": 10, "plain": 2}, calls               # every pass but the first
+        for a, b in zip(got, want + want):
+            assert torch.equal(a, b)
+        # written in place: the ordinary order, and the new values
+        calls.update(early=0, plain=0)
+        feats["fea_up2"].mul_(1.25)
+        got = passes(feats)
+        assert calls == {"early": 4, "plain": 2}, calls
+        hip.set_cross_pass_overlap(False)
+        want2 = passes(feats)
+        hip.set_cross_pass_overlap(True)
+        assert not torch.equal(want2[0], want[0])
+        for a, b in zip(got, want2):
+            assert torch.equal(a, b)
+        # new tensor objects with the same values
+        calls.update(early=0, plain=0)
+        clone = {k: v.clone() for k, v in feats.items()}
+        z, _ = fu(gt=x1, rrdbResults=clone, logdet=ld0, reverse=False)
+        assert calls == {"early": 0, "plain": 2} and torch.equal(z, want2[0])
+        # a tensor the layer has to convert (non-contiguous) is never early
+        calls.update(early=0, plain=0)
+        nc = {k: v.transpose(2, 3).contiguous().transpose(2, 3) for k, v in feats.items()}
+        for _ in range(2):
+            z, _ = fu(gt=x1, rrdbResults=nc, logdet=ld0, reverse=False)
+            assert torch.equal(z, want2[0])
+        assert calls == {"early": 0, "plain": 4}, calls
+        # tensors made under inference mode keep no version counter: never early
+        calls.update(early=0, plain=0)
+        with torch.inference_mode():
+            inf = {k: v.clone() for k, v in feats.items()}
+            for _ in range(2):
+                z, _ = fu(gt=x1, rrdbResults=inf, logdet=ld0, reverse=False)
+                assert torch.equal(z, want2[0])
+        assert calls == {"early": 0, "plain": 4}, calls
+        # the one-stream schedule: the flag is honoured (the pass waits for the early loads), same bits
+        hip.set_schedule(aux_stream=0)
+        try:
+            got = passes(feats) + passes(feats)
+        finally:
+            hip.set_schedule(aux_stream=1)
+        for a, b in zip(got, want2 + want2):
+            assert torch.equal(a, b)
+    finally:
+        hip.set_cross_pass_overlap(prev)
 
 
 def test_quantize_u8_bit_exact():

@@ -20,7 +20,15 @@ with torch.no_grad():
     for _ in range(3):
         model.flow_upsampler.prepare_cond(feats, B, PATCH, PATCH)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        model.flow_upsampler.prepare_cond(feats, B, PATCH, PATCH)
+    e1.record(); torch.cuda.synchronize()
+    print("prepare_cond: %.3f ms per call" % (e0.elapsed_time(e1) / 10))
 L = hip.lib()
+if not hasattr(L, "ifl_dbgx_read"):
+    sys.exit(0)
 nwg = 8192
 buf = np.zeros(nwg * 8 * 8, np.uint64)
 L.ifl_dbgx_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
