@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cross-pass-overlap", action="store_true",
                     help="every pass's bulk convolutions behind the whole previous pass (the plain stream order) instead of behind "
                          "its bulk convolutions only (hip.set_cross_pass_overlap: passes in a row on unchanged conditioning tensors)")
+    ap.add_argument("--no-hires", action="store_true", help="skip the secondary `config4_512_bf16` measurement (512x512 patches, bf16 convolutions)")
     ap.add_argument("--breakdown", action="store_true", help="(kept for old command lines: the breakdown is on by default)")
     args = ap.parse_args()
 
@@ -176,6 +177,38 @@ def main():
             bf16 = {"elapsed": bf_elapsed, "dom_ms": b_ms, "dom_n": b_n,
                     "round_trip_err": float((ob[2] - x).abs().max()),
                     "z_rel_err_vs_fp32": float((ob[0] - z).abs().max() / z.abs().max())}
+        hires = None
+        if secondary and not args.no_hires:
+            # Secondary figure (never `value`): BASELINE.json configs[4] -- 512x512 patches, the coupling networks' z-independent
+            # convolutions on the bf16 matrix cores (conv_dtype "bf16": fp32 ActNorm / log-det / couplings / 1x1 maps).
+            HB, HP, hsteps = 4, 512, 5
+            gen = torch.Generator(device=dev).manual_seed(3000 + rank)
+            hx = torch.rand(HB, 3, HP, HP, device=dev, generator=gen)
+            hf = {"fea_up2": (torch.rand(HB, 320, HP // 2, HP // 2, device=dev, generator=gen) - 0.5) * 12 ** 0.5,
+                  "fea_up1": (torch.rand(HB, 320, HP // 4, HP // 4, device=dev, generator=gen) - 0.5) * 12 ** 0.5,
+                  "fea_up4": torch.zeros(1, device=dev)}
+
+            def hstep():
+                hz, _ = model(hx, None, lr_enc=hf, add_gt_noise=False, calc_loss=False)
+                return model(hz, hx, reverse=True, lr_enc=hf, add_gt_noise=False, test_input_size=HP)
+            model.flow_upsampler.conv_dtype = "bf16"
+            try:
+                hstep(); hstep()
+                barrier()
+                hip.prof_enable([hip.K_CONV1_FT_L1])
+                t4 = time.perf_counter()
+                for _ in range(hsteps):
+                    hxr, _ = hstep()
+                barrier()
+                h_elapsed = shard.max_over_ranks(time.perf_counter() - t4, dist, dev)
+                h_ms, h_n = hip.prof_read(hip.K_CONV1_FT_L1)
+                hip.prof_enable([])
+            finally:
+                model.flow_upsampler.conv_dtype = "fp32"
+            hires = {"elapsed": h_elapsed, "dom_ms": h_ms, "dom_n": h_n, "B": HB, "P": HP, "steps": hsteps,
+                     "round_trip_err": float((hxr - hx).abs().max())}
+            del hx, hf, hxr
+            hip.Workspace.clear()
         if secondary:
             # (1) the same steps with everything on ONE stream: kernels strictly one after another, so the dominant
             #     kernel's duration is free of time-sharing with the per-step chain; (2) one step with every kernel timed
@@ -282,6 +315,21 @@ def main():
                                                              "peak_tflops": 2500.0},
                                  "z_rel_err_vs_fp32": bf16["z_rel_err_vs_fp32"], "roundtrip_max_abs_err": bf16["round_trip_err"],
                                  "note": "secondary, NOT the metric (BASELINE.json configs[4] arithmetic on the configs[1] workload)"}
+        if hires:
+            hfl = 2.0 * macs_px_direct * (hires["P"] // 2) ** 2 * hires["B"] * 16 * 2 * hires["steps"] / max(hires["dom_n"], 1)
+            h_avg = hires["dom_ms"] / max(hires["dom_n"], 1)
+            res["config4_512_bf16"] = {
+                "value": world * hires["B"] * hires["steps"] / hires["elapsed"], "unit": "512x512 patches/s",
+                "patches_160_equivalent_per_s": world * hires["B"] * hires["steps"] / hires["elapsed"] * (hires["P"] / PATCH) ** 2,
+                "ms_per_step": hires["elapsed"] / hires["steps"] * 1e3, "steps": hires["steps"], "batch_per_gpu": hires["B"],
+                "dtype": "bf16 operands / f32 accumulate in the coupling networks' z-independent convolutions (conv1_ft, fFeatures' "
+                         "1x1 and last conv); f32 ActNorm, log-det, couplings, invertible 1x1 maps and fAffine's z-dependent chain",
+                "roofline": {"bound": "mfma", "kernel": "conv1_ft_bf16 (level 1, direct implicit GEMM, v_mfma_f32_32x32x16_bf16)",
+                             "avg_launch_ms": h_avg, "launches": hires["dom_n"], "achieved": hfl / (h_avg * 1e-3) / 1e12,
+                             "peak": 2500.0, "unit": "TFLOP/s", "frac": hfl / (h_avg * 1e-3) / 1e12 / 2500.0},
+                "roundtrip_max_abs_err": hires["round_trip_err"],
+                "note": "secondary, NOT the metric: BASELINE.json configs[4] (high-res 512x512 patches, bf16 coupling-NN convs with "
+                        "fp32 ActNorm/logdet) per GPU; encode + decode, measured after the timed region"}
         if serial:
             res["serial_schedule"] = serial
             res["serial_schedule"]["dominant_tflops_alone"] = flops_launch / (serial["dominant_avg_launch_ms"] * 1e-3) / 1e12
