@@ -454,6 +454,66 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// fFeatures' epilogue of the bf16 kernels: ActNorm + ReLU (fp32), 1x1 conv on the bf16 matrix cores straight from the
+// accumulators (rounded to bf16; the 1x1 weights are packed in the accumulator rows' k order), ActNorm + ReLU, store
+template <int NT>
+__device__ __forceinline__ void bf16_finish_and_store(f32x16 (&acc)[2][NT], const float* __restrict__ an1, const bf16x8* w2,
+                                                      const float* __restrict__ an2, float* __restrict__ h2P,
+                                                      const int64_t (&opix)[NT], int h)
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4 bb[4], ss[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bb[q] = *(const f32x4*)(an1 + (m * 2 + h) * 16 + q * 4);
+            ss[q] = *(const f32x4*)(an1 + 64 + (m * 2 + h) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[m][n][r] + bb[r >> 2][r & 3]) * ss[r >> 2][r & 3];
+                acc[m][n][r] = v > 0.f ? v : 0.f;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x16 y[2];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[m2][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 xk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xk[e] = (__bf16)acc[m][n][8 * s2 + e];
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma_bf16(w2[((m2 * 2 + m) * 2 + s2) * 64], xk, y[m2]);
+            }
+        if (opix[n] >= 0) {
+            float* dst = h2P + IFL_HID + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 bb = *(const f32x4*)(an2 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 ss = *(const f32x4*)(an2 + 64 + (m2 * 2 + h) * 16 + gq * 4);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (y[m2][gq * 4 + e] + bb[e]) * ss[e];
+                        o[e] = v > 0.f ? v : 0.f;
+                    }
+                    *(f32x4*)(dst + m2 * 32 + gq * 8) = o;
+                }
+        }
+    }
+}
+
 template <int LVL>
 __global__ __launch_bounds__(256, 2)
 void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
@@ -569,61 +629,150 @@ void conv1_ft_bf16_kernel(const float* __restrict__ ftP, float* __restrict__ h2a
         }
         return;
     }
-    // fFeatures: ActNorm + ReLU (fp32), 1x1 conv on the bf16 matrix cores straight from the accumulators, ActNorm + ReLU
-    const float* an1 = prm + off.an1[1];
-    const float* an2 = prm + off.an2[1];
+    bf16_finish_and_store<NT>(acc, prm + off.an1[1], (const bf16x8*)(prm + off.w2b) + lane, prm + off.an2[1], h2P, opix, h);
+}
+
+// ---- bf16 phase 1, region form (default for the bf16 variant) --------------------------------------------------------------
+// conv1_ft_bf16_kernel streams 2 KB of weight fragments per wave for 4 MFMAs (64 B per clock and CU at the matrix cores'
+// rate: twice what a CU ingests), which holds it at 0.30 of the bf16 peak.  Here a wave keeps 64 outputs x 128 pixels
+// (8 accumulators of 32x32), so a weight fragment serves 4 MFMAs and the stream halves; to make 128 pixels per wave
+// affordable the workgroup's pixels are a 16 x 16 REGION (patch 18 x 18 = 324 pixels, about the band form's 304 for half
+// as many pixels): 4 waves = 2 networks x 2 halves (8 rows) of the region, MFMA pixel tile n of a wave = 2 rows x 16
+// (an 8 x 32 region with one-row tiles -- conflict-free LDS reads by construction -- measures the same at 512 x 512 and wastes
+// more lanes on the 80- and 40-pixel planes of 160 x 160 patches).
+// The patch is loaded, rounded to bf16 and stored to LDS between the two barriers of a chunk (no register prefetch: the
+// accumulators take half the register file); the CU's second workgroup multiplies meanwhile.
+constexpr int RBW = 16, RBH = 16;             // region width, height
+constexpr int RBP = RBW + 2;                  // patch width (height RBH + 2)
+constexpr int RB_PX = RBP * (RBH + 2);        // patch pixels (324)
+constexpr int RB_SLOTS = (RB_PX * 8 + 255) / 256;          // float4 loads per thread per chunk (11)
+constexpr int RB_SG = 4;                      // steps whose workgroups of one region run side by side on an XCD
+
+template <int LVL>
+__global__ __launch_bounds__(256, 2)
+void conv1_ft_bf16r_kernel(const float* __restrict__ ftP, float* __restrict__ h2all, int64_t h2_step_stride,
+                           const float* __restrict__ params, IflStepList steps, IflStepOff off, int H, int W, int nimg, int nsteps)
+{
+    constexpr int NT = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RB_SLOTS * 32 * CSB];
+    // Workgroup -> (step, image, region).  Consecutive workgroup ids go to consecutive XCDs; within an XCD the steps of one
+    // launch are the fastest index, so the workgroups that stage the SAME patch (one per step) run side by side on one XCD and
+    // all but the first find it in that XCD's L2 (otherwise every step re-reads the conditioning features from HBM: at 512 x 512
+    // 2.2 TB/s of them); the launch's weights (4 steps x 2 networks x 368 KB) stay in the 4 MB L2 as well.
+    const int gx = (W + RBW - 1) / RBW;
+    const int nreg = gx * ((H + RBH - 1) / RBH);
+    // (groups of RB_SG steps, one group after the other, when a launch holds more)
+    const int per_group = (nreg * nimg + 7) / 8 * 8 * RB_SG;
+    const int grp_ = blockIdx.x / per_group, loc_ = blockIdx.x - grp_ * per_group, t_ = loc_ >> 3;
+    const int step = grp_ * RB_SG + t_ % RB_SG, rb = (t_ / RB_SG) * 8 + (loc_ & 7);
+    if (rb >= nreg * nimg || step >= nsteps) return;
+    const int b = rb / nreg, reg = rb - b * nreg;
+    const int ry0 = (reg / gx) * RBH, rx0 = (reg % gx) * RBW;                      // the region's pixel (0, 0), plane coordinates
+    const float* prm = params + steps.off[step];
+    float* h2P = h2all + (int64_t)step * h2_step_stride;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int net = wave & 1, part = wave >> 1;
+    const int W2 = W + 2;
+
+    // tile n of this wave: pixels (part * 8 + 2 n + (j >> 4), j & 15) of the region; patch pixel (r, c) is pixel (r, c)'s top-left tap
+    const int a00 = ((part * 8 + (j >> 4)) * RBP + (j & 15)) * CSB + 16 * h;      // tile n: + n * 2 * RBP * CSB
+
+    // patch pixel (r, c) = ring pixel (ry0 + r, rx0 + c); outside the ringed plane (partial regions): pixel (0, 0) of the ring, a zero
+    // (buffer loads: descriptor + 32-bit lane offset + scalar offset, no 64-bit address arithmetic or address registers)
+    const float* ft_b = ftP + (int64_t)b * (H + 2) * W2 * IFL_FT;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)ft_b, 0, (H + 2) * W2 * IFL_FT * 4, 0x00020000);
+    int srcoff[RB_SLOTS];                     // bytes
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        f32x4 bb[4], ss[4];
+    for (int i = 0; i < RB_SLOTS; ++i) {
+        const int idx = tid + i * 256;
+        const int p = idx >> 3, q = idx & 7;
+        const int r = p / RBP, c = p - r * RBP;
+        const bool in = p < RB_PX && ry0 + r <= H + 1 && rx0 + c <= W + 1;
+        srcoff[i] = (in ? ((ry0 + r) * W2 + rx0 + c) * IFL_FT + q * 4 : q * 4) * 4;
+    }
+
+    f32x16 acc[2][NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bb[q] = *(const f32x4*)(an1 + (m * 2 + h) * 16 + q * 4);
-            ss[q] = *(const f32x4*)(an1 + 64 + (m * 2 + h) * 16 + q * 4);
-        }
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (acc[m][n][r] + bb[r >> 2][r & 3]) * ss[r >> 2][r & 3];
-                acc[m][n][r] = v > 0.f ? v : 0.f;
-            }
-    }
-    const bf16x8* w2 = (const bf16x8*)(prm + off.w2b) + lane;      // block ((m2*2 + m)*2 + s) at w2[.. * 64]
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    constexpr int WD = 3;
+    constexpr int ITERS = 18;                 // 9 taps x 2 k-steps of 16 channels per chunk
+    static_assert(ITERS % WD == 0, "ring slots must be compile-time");
+    // weight block bi (one MFMA A fragment for every lane) at byte bi * 1024 of the network's bf16 copy; reads past its end
+    // (the ring's last refills) return zeros
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(prm + off.w1b[net]), 0, NCC * ITERS * 2 * 1024, 0x00020000);
+    auto load_w = [&](int bi) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, bi * 1024, 0)); };
+    bf16x8 wq[WD][2];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        f32x16 y[2];
+    for (int d = 0; d < WD; ++d)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
+        for (int m = 0; m < 2; ++m) wq[d][m] = load_w(d * 2 + m);
+
+    auto load_patch = [&](f32x4 (&stage)[RB_SLOTS], int cc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[m2][r] = 0.f;
+        for (int i = 0; i < RB_SLOTS; ++i) {
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, srcoff[i], cc * (IFL_CK * 4), 0));
+        }
+    };
+    f32x4 stage[RB_SLOTS];
+    load_patch(stage, 0);
+    for (int cc = 0; cc < NCC; ++cc) {
+        __syncthreads();                      // the previous chunk's LDS reads are over
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < RB_SLOTS; ++i) {
+            const int idx = tid + i * 256;
+            bf16x4 v;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 xk;
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)stage[i][e];
+            if (idx < RB_PX * 8) *(bf16x4*)&lds[(idx >> 3) * CSB + (idx & 7) * 8] = v;
+        }
+        __syncthreads();
+        if (cc + 1 < NCC) load_patch(stage, cc + 1);        // in flight beside this chunk's MFMAs
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xk[e] = (__bf16)acc[m][n][8 * s2 + e];
+        for (int it = 0; it < ITERS; ++it) {
+            const int tap = it >> 1, ks = it & 1;
+            const int tapoff = ((tap / 3) * RBP + (tap % 3)) * CSB;
+            bf16x8 xb[NT];
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) y[m2] = mfma_bf16(w2[((m2 * 2 + m) * 2 + s2) * 64], xk, y[m2]);
-            }
-        if (opix[n] >= 0) {
-            float* dst = h2P + IFL_HID + opix[n] * IFL_H2 + 4 * h;
+            for (int n = 0; n < NT; ++n) xb[n] = *(const bf16x8*)(lds + a00 + n * (2 * RBP * CSB) + tapoff + ks * 32);
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    f32x4 bb = *(const f32x4*)(an2 + (m2 * 2 + h) * 16 + gq * 4);
-                    f32x4 ss = *(const f32x4*)(an2 + 64 + (m2 * 2 + h) * 16 + gq * 4);
-                    f32x4 o;
+                for (int m = 0; m < 2; ++m) acc[m][n] = mfma_bf16(wq[it % WD][m], xb[n], acc[m][n]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = (y[m2][gq * 4 + e] + bb[e]) * ss[e];
-                        o[e] = v > 0.f ? v : 0.f;
-                    }
-                    *(f32x4*)(dst + m2 * 32 + gq * 8) = o;
-                }
+            for (int m = 0; m < 2; ++m) wq[it % WD][m] = load_w((cc * ITERS + it + WD) * 2 + m);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+
+    int64_t opix[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = part * 8 + n * 2 + (j >> 4), c = j & 15;
+        opix[n] = (ry0 + r < H && rx0 + c < W) ? ((int64_t)(b * (H + 2) + ry0 + r + 1) * W2 + rx0 + c + 1) : -1;
+    }
+    if (net == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (opix[n] < 0) continue;
+            float* dst = h2P + opix[n] * IFL_H2 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *(f32x4*)(dst + m * 32 + gq * 8) = f32x4{acc[m][n][gq * 4], acc[m][n][gq * 4 + 1],
+                                                             acc[m][n][gq * 4 + 2], acc[m][n][gq * 4 + 3]};
+        }
+        return;
+    }
+    bf16_finish_and_store<NT>(acc, prm + off.an1[1], (const bf16x8*)(prm + off.w2b) + lane, prm + off.an2[1], h2P, opix, h);
 }
 
 // ---- phase 2: fAffine's z1 taps + its epilogue --------------------------------------------------------------------
@@ -834,7 +983,16 @@ int ifl_k_conv1_ft(const float* ft, float* h2all, int64_t h2_step_stride, const 
     if (nsteps <= 0) return 0;
     dim3 grid(g.ntiles, B, nsteps), block(256);
     if (bf16) {
-        if (level == 1) hipLaunchKernelGGL(conv1_ft_bf16_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
+        static const int region_form = [] { const char* e = getenv("IFL_BF16_REGION"); return e ? atoi(e) : 1; }();
+        if (region_form) {
+            const int64_t nrb = (int64_t)((g.H + RBH - 1) / RBH) * ((g.W + RBW - 1) / RBW) * B;
+            const int64_t nwg = (nrb + 7) / 8 * 8 * RB_SG * ((nsteps + RB_SG - 1) / RB_SG);
+            if (nwg >= (int64_t)1 << 31) { ifl_set_error("conv1_ft (bf16): %lld workgroups exceed the grid", (long long)nwg); return IFL_ENOTSUP; }
+            dim3 rgrid((unsigned)nwg);
+            if (level == 1) hipLaunchKernelGGL(conv1_ft_bf16r_kernel<1>, rgrid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g.H, g.W, B, nsteps);
+            else hipLaunchKernelGGL(conv1_ft_bf16r_kernel<2>, rgrid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g.H, g.W, B, nsteps);
+        }
+        else if (level == 1) hipLaunchKernelGGL(conv1_ft_bf16_kernel<1>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
         else hipLaunchKernelGGL(conv1_ft_bf16_kernel<2>, grid, block, 0, st, ft, h2all, h2_step_stride, params, steps, off, g);
         IFL_LAUNCH_CHECK();
         return 0;
