@@ -67,27 +67,29 @@ __device__ __forceinline__ s16x4 to_bf16(f32x4 v) {
 // BF16: the products run on v_mfma_f32_16x16x16_bf16 -- a lane's four k-steps (channels 4q .. 4q+3 of the sub-chunk) are one
 // instruction -- with both operands (transformed weights U, transformed activations V) rounded to bf16, fp32 accumulate; the
 // transforms, bias / exp / sigmoid and the coupling stay fp32 (BASELINE.json configs[4]).
-template <int MODE, bool BF16>
-__global__ __launch_bounds__(256, 3)
+// NTW: row tiles per workgroup.  2 (fFeatures at C = 12: both of its tiles): the patch is staged and transformed once for
+// both, 32 accumulators per lane, two workgroups per CU instead of three.
+template <int MODE, bool BF16, int NTW = 1>
+__global__ __launch_bounds__(256, NTW == 1 ? 3 : 2)
 void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstride, float* sfAll, int64_t sf_step,
                    float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots, int slot0,
                    const float* __restrict__ params, IflStepList steps, int64_t w3w_off, int64_t b3_off, int NT, int NA,
                    int H, int W, int C, float eps)
 {
     __shared__ __attribute__((aligned(16))) float patch[PWD * PRS];
-    __shared__ __attribute__((aligned(16))) float us[USZ];
+    __shared__ __attribute__((aligned(16))) float us[NTW * USZ];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int b = blockIdx.y;
-    const int step = blockIdx.z / NT, rt = blockIdx.z - step * NT;
+    const int step = blockIdx.z / (NT / NTW), rt0 = (blockIdx.z - step * (NT / NTW)) * NTW;      // row tiles rt0 .. rt0 + NTW - 1
     const int gx = (W + RGN - 1) / RGN;
     const int wgy = blockIdx.x / gx, wgx = blockIdx.x - wgy * gx;
     const int W2 = W + 2;
     const float* prm = params + steps.off[step];
     const float* src = srcAll + (int64_t)step * src_step + (int64_t)b * (H + 2) * W2 * pstride;
-    const float* wsrc = prm + w3w_off + (int64_t)rt * (4 * USZ);
+    const float* wsrc = prm + w3w_off + (int64_t)rt0 * (4 * USZ);                  // tile rt0 + tw: + tw * 4 * USZ
 
     // ---- staging plan: per-thread source offsets of the patch (same for every sub-chunk) ----
     int poff[NPF];                            // float offset inside the image's plane, or -1 (outside the ringed plane / past the patch)
@@ -101,20 +103,24 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
         poff[k] = ok ? (gy_ * W2 + gx_) * pstride + qd * 4 : -1;
         pdst[k] = px < PPX ? pr * PRS + pc * PST + qd * 4 : -1;
     }
-    f32x4 pre[NPF], upre[4];
+    f32x4 pre[NPF], upre[NTW][4];
     auto prefetch = [&](int s) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
             pre[k] = poff[k] >= 0 ? *(const f32x4*)(src + poff[k] + s * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) upre[k] = *(const f32x4*)(wsrc + s * USZ + (tid + k * 256) * 4);
+        for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) upre[tw][k] = *(const f32x4*)(wsrc + tw * (4 * USZ) + s * USZ + (tid + k * 256) * 4);
     };
     auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
             if (pdst[k] >= 0) *(f32x4*)&patch[pdst[k]] = pre[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(f32x4*)&us[(tid + k * 256) * 4] = upre[k];
+        for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(f32x4*)&us[tw * USZ + (tid + k * 256) * 4] = upre[tw][k];
     };
 
     // ---- this lane's tile ----
@@ -124,9 +130,11 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
     const int wbase = (4 * wave + 2 * ty) * PRS + 2 * tx * PST + 4 * q;                   // window pixel (r, c): + r * PRS + c * PST
     const int abase = q * 64 + j * 4;                                                     // A fragment of position p: + p * 256
 
-    f32x4 acc[16];
+    f32x4 accs[NTW][16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) accs[tw][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     prefetch(0);
     for (int s = 0; s < 4; ++s) {
@@ -145,17 +153,24 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
 #pragma unroll
             for (int i = 0; i < 4; ++i) bt4(v[i][0], v[i][1], v[i][2], v[i][3]);          // along the columns: v[i][jc]
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const f32x4 a = *(const f32x4*)&us[abase + p * 256];
-                if (BF16) acc[p] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16(a), to_bf16(v[p >> 2][p & 3]), acc[p], 0, 0, 0);
-                else {
+            for (int p = 0; p < 16; ++p)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[p] = mfma16w(a[e], v[p >> 2][p & 3][e], acc[p]);
+                for (int tw = 0; tw < NTW; ++tw) {
+                    const f32x4 a = *(const f32x4*)&us[tw * USZ + abase + p * 256];
+                    if (BF16) accs[tw][p] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16(a), to_bf16(v[p >> 2][p & 3]), accs[tw][p], 0, 0, 0);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accs[tw][p] = mfma16w(a[e], v[p >> 2][p & 3][e], accs[tw][p]);
+                    }
                 }
-            }
         }
     }
 
+    const int nwg = gridDim.x;
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+    const int rt = rt0 + tw;
+    const f32x4 (&acc)[16] = accs[tw];
     // ---- output transform: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
     f32x4 y[2][2];
     {
@@ -255,9 +270,10 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
     for (int o = 32; o > 0; o >>= 1) ld += __shfl_xor(ld, o, 64);
     if (lane == 0) red[wave] = ld;
     __syncthreads();
-    const int nwg = gridDim.x;
     if (tid == 0)
         ldpart[(int64_t)b * ld_slots + slot0 + (step * NT + rt) * nwg + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (NTW > 1) __syncthreads();             // red[] is reused by the next tile
+    }
 }
 
 }  // namespace
@@ -278,11 +294,15 @@ int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, floa
     const int NT = mode == W3_F ? NF : NA;
     const int nwg = ifl_w3_wgs(H, W);
     if ((int64_t)(H + 2) * (W + 2) * pstride >= (int64_t)1 << 31) { ifl_set_error("conv3 (Winograd): plane too large for 32-bit offsets"); return IFL_ENOTSUP; }
-    dim3 grid(nwg, B, nsteps * NT), block(256);
+    // fFeatures, fp32: two row tiles per workgroup (C = 12: both; C = 48: three pairs; IFL_CONV3_F_PAIR=0: one each; +0.7 % and +0.4 %)
+    static const int f_pair = [] { const char* e = getenv("IFL_CONV3_F_PAIR"); return e ? atoi(e) : 3; }();     // bit 0: C = 12, bit 1: C = 48
+    const int ntw = (mode == W3_F && !bf16 && NT % 2 == 0 && (f_pair & (NT == 2 ? 1 : 2))) ? 2 : 1;
+    dim3 grid(nwg, B, nsteps * (NT / ntw)), block(256);
     const int64_t w3w = off.w3w[mode == W3_F ? 1 : 0], b3 = off.b3[mode == W3_F ? 1 : 0];
-#define IFL_W3_LAUNCH(M, BF) hipLaunchKernelGGL((conv3w_kernel<M, BF>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, \
+#define IFL_W3_LAUNCH(M, BF, ...) hipLaunchKernelGGL((conv3w_kernel<M, BF, ##__VA_ARGS__>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, \
                                                 ld_slots, slot0, params, steps, w3w, b3, NT, NA, H, W, C, eps)
-    if (mode == W3_F) { if (bf16) IFL_W3_LAUNCH(W3_F, true); else IFL_W3_LAUNCH(W3_F, false); }
+    if (mode == W3_F && ntw == 2) IFL_W3_LAUNCH(W3_F, false, 2);
+    else if (mode == W3_F) { if (bf16) IFL_W3_LAUNCH(W3_F, true); else IFL_W3_LAUNCH(W3_F, false); }
     else if (mode == W3_ENC) { if (bf16) IFL_W3_LAUNCH(W3_ENC, true); else IFL_W3_LAUNCH(W3_ENC, false); }
     else if (mode == W3_DEC) { if (bf16) IFL_W3_LAUNCH(W3_DEC, true); else IFL_W3_LAUNCH(W3_DEC, false); }
     else { ifl_set_error("conv3 (Winograd): mode %d", mode); return IFL_EINVAL; }
