@@ -402,6 +402,7 @@ struct ForkCtx {
                          // streams on one device are correct as long as their enqueue sequences do not interleave
     bool ok = false;
     hipStream_t aux, s[IFL_MAX_GROUPS - 1];
+    int n_s = 0;         // group streams created so far
     hipEvent_t fork, aux_done, early, join[IFL_MAX_GROUPS - 1], p1[MAX_P1_EVENTS];
 };
 ForkCtx g_fork[IFL_MAX_DEVICES];
@@ -420,10 +421,10 @@ int fork_ctx(ForkCtx** out, std::unique_lock<std::mutex>* lock)
         // the bulk stream gets the high priority: its long workgroups then take a freed CU before the chain's short ones,
         // which measures 1 % faster than the opposite choice (IFL_AUX_PRIO_HIGH=0) with the F(4x4) bulk kernel
         IFL_HIP(hipStreamCreateWithPriority(&f.aux, hipStreamNonBlocking, env_int("IFL_AUX_PRIO_HIGH", 1) ? hi : lo));
-        for (int i = 0; i < IFL_MAX_GROUPS - 1; ++i) {
-            IFL_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
-            IFL_HIP(hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming));
-        }
+        // (the sample groups' streams are created when a call first uses them: HIP deals its streams to 4 hardware queues
+        // (GPU_MAX_HW_QUEUES) in creation order, and two busy streams on one queue serialise -- a sixth stream for the early
+        // conditioning loads, sharing the bulk stream's queue, cost 7 % of the step)
+        for (int i = 0; i < IFL_MAX_GROUPS - 1; ++i) IFL_HIP(hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming));
         for (int i = 0; i < MAX_P1_EVENTS; ++i) IFL_HIP(hipEventCreateWithFlags(&f.p1[i], hipEventDisableTiming));
         IFL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
         IFL_HIP(hipEventCreateWithFlags(&f.aux_done, hipEventDisableTiming));
@@ -687,6 +688,7 @@ int run_flow(bool decode, bool prepared, int bf16, const ifl_layer* layers, int 
     }
     if (use_aux) IFL_HIP(hipEventRecord(f->aux_done, f->aux));
     else if (G > 1) IFL_HIP(hipEventRecord(f->fork, st));        // groups start after phase 1 on the caller's stream
+    for (; f->n_s < G - 1; ++f->n_s) IFL_HIP(hipStreamCreateWithFlags(&f->s[f->n_s], hipStreamNonBlocking));
     for (int g = 0; g < G; ++g) {
         const int b0 = (int)((int64_t)B * g / G), b1 = (int)((int64_t)B * (g + 1) / G);
         hipStream_t sg = g == 0 ? st : f->s[g - 1];
@@ -820,7 +822,9 @@ extern "C" int ifl_load_cond_early(void* ws, int B, int H, int W, int level, con
     std::unique_lock<std::mutex> fork_lock;
     if ((rc = fork_ctx(&f, &fork_lock))) return rc;
     // behind the entry of the previous pass on its calling stream (where, by the caller's promise, the features were complete)
-    // -- the bulk stream is already there unless that pass ran on the one-stream schedule -- and behind `after_event`
+    // -- the bulk stream is already there unless that pass ran on the one-stream schedule -- and behind `after_event`.
+    // (On a stream of their own the conversions run beside the previous pass's bulk kernels: +0.5 % of the step, but they
+    // stretch the dominant launch from 1.64 to 1.71 ms; measured with 4 streams in all, see fork_ctx -- not kept.)
     IFL_HIP(hipStreamWaitEvent(f->aux, f->fork, 0));
     if (after_event) IFL_HIP(hipStreamWaitEvent(f->aux, (hipEvent_t)after_event, 0));
     if ((rc = load_ft(w.lv[level - 1], B, ft_nchw, f->aux))) return rc;
