@@ -166,7 +166,8 @@ int ifl_flow_pass(const ifl_layer* layers, int n_layers, const float* params, vo
  *   groups          1..4 contiguous sample groups whose chains run on separate library-owned streams.
  *   p1_chunk_steps  conditional steps per bulk launch (1..16), all levels.
  * A negative / zero value keeps the current setting.  Defaults: 1, 2, 4 at the first level and 8 below (environment IFL_AUX_STREAM, IFL_GROUPS,
- * IFL_P1_CHUNK_STEPS and, for the levels below the first, IFL_P1_CHUNK_STEPS_L2 override them at load).  Results do not depend on the schedule.  The library-owned streams and
+ * IFL_P1_CHUNK_STEPS and, for the levels below the first, IFL_P1_CHUNK_STEPS_L2 override them at load; a pass started with
+ * IFL_FLOW_COND_EARLY launches 8 first-level steps at a time, IFL_P1_CHUNK_STEPS_EARLY).  Results do not depend on the schedule.  The library-owned streams and
  * events are created once per device at the first call that needs them.                                            */
 int ifl_set_schedule(int aux_stream, int groups, int p1_chunk_steps);
 
