@@ -332,7 +332,10 @@ def main():
                         "fp32 ActNorm/logdet) per GPU; encode + decode, measured after the timed region"}
         if serial:
             res["serial_schedule"] = serial
-            res["serial_schedule"]["dominant_tflops_alone"] = flops_launch / (serial["dominant_avg_launch_ms"] * 1e-3) / 1e12
+            # (the one-stream schedule launches 4 first-level steps at a time, the timed region 8: price each at its own launch count)
+            serial_flops_launch = flops_total / args.steps * serial["steps"] / max(s_n, 1)
+            res["serial_schedule"]["dominant_steps_per_launch"] = round(32 * serial["steps"] / max(s_n, 1))
+            res["serial_schedule"]["dominant_tflops_alone"] = serial_flops_launch / (serial["dominant_avg_launch_ms"] * 1e-3) / 1e12
             res["serial_schedule"]["dominant_frac_alone"] = res["serial_schedule"]["dominant_tflops_alone"] / PEAK_F32_MFMA_TFLOPS
             res["kernels_ms_per_step"] = {k: v[0] for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
