@@ -186,7 +186,9 @@ void conv1_ft_wino4_kernel(const float* __restrict__ vg, float* __restrict__ h2a
             // launches of more than 8 pairs (8 steps: passes started early): the sets of 8 pairs are the fastest index, so an XCD
             // runs steps s and s + 4 of a tile group side by side and the group's images pass through its L2 once for both
             // (dominant launch 3.22 -> 3.08 ms in situ)
-            const int x = id & 7, t = id >> 3, nset = ncombo >> 3, set = t % nset, tl = t / nset;
+            // (two sets at a time: four -- ifl_cond_prepare's 16-step launches -- put eight filter banks through an XCD's L2 at once)
+            const int x = id & 7, t = id >> 3, nset = ncombo >> 3, il = (nset & 1) ? 1 : 2;
+            const int rest = t / il, tl = rest % ngroups, set = (rest / ngroups) * il + t % il;
             grp = (tl >> 1) * 2 + (x >> 2);
             combo = set * 8 + (x & 3) * 2 + (tl & 1);
         }
