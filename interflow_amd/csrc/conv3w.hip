@@ -107,11 +107,19 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
     auto prefetch = [&](int s) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
+#ifdef IFL_EXP3_NOSTAGE
+            pre[k] = f32x4{1.f * poff[k], 0.5f, 0.25f, 1.f * s};
+#else
             pre[k] = poff[k] >= 0 ? *(const f32x4*)(src + poff[k] + s * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int tw = 0; tw < NTW; ++tw)
 #pragma unroll
+#ifdef IFL_EXP3_NOSTAGE
+            for (int k = 0; k < 4; ++k) upre[tw][k] = f32x4{0.001f * tid, 0.5f, 0.25f, 1.f * s};
+#else
             for (int k = 0; k < 4; ++k) upre[tw][k] = *(const f32x4*)(wsrc + tw * (4 * USZ) + s * USZ + (tid + k * 256) * 4);
+#endif
     };
     auto commit = [&]() {
 #pragma unroll
@@ -148,10 +156,12 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[r][c] = *(const f32x4*)&patch[wbase + r * PRS + c * PST];
+#ifndef IFL_EXP3_NOXFORM
 #pragma unroll
             for (int c = 0; c < 4; ++c) bt4(v[0][c], v[1][c], v[2][c], v[3][c]);          // along the rows: v[i][c]
 #pragma unroll
             for (int i = 0; i < 4; ++i) bt4(v[i][0], v[i][1], v[i][2], v[i][3]);          // along the columns: v[i][jc]
+#endif
 #pragma unroll
             for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -167,6 +177,17 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
     }
 
     const int nwg = gridDim.x;
+#ifdef IFL_EXP3_NOEPI
+    if (MODE == W3_F) {
+        float sum = 0.f;
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) sum += accs[tw][p][0] + accs[tw][p][1] + accs[tw][p][2] + accs[tw][p][3];
+        if (sum == 12345.678f) sfAll[tid] = sum;
+        return;
+    }
+#endif
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
     const int rt = rt0 + tw;
