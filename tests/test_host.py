@@ -164,3 +164,42 @@ def test_multi_level_configurations_build_with_split2d(correct_splits, channels)
     with pytest.raises(NotImplementedError):
         FlowUpsamplerNet((160, 160, 3), 64, K, flow_coupling='CondAffineSeparatedAndCond', LU_decomposed=True, opt=opt)
     assert not InterpFlow([2, 4]).flow_upsampler._general        # the shipped configuration stays on the fused driver
+
+
+def test_unchanged_conditioning_is_recognised_by_object_version_and_layout(model):
+    """hip.set_cross_pass_overlap: a pass may start its bulk work early only if every conditioning tensor is the very object the
+    previous pass loaded, unwritten since (version counter), at the same address, float32 and contiguous (host logic of
+    FlowUpsamplerNet._cond_unchanged / _remember_cond; the GPU side is tests/test_gpu_parity.py)."""
+    fu = model.flow_upsampler
+    saved = fu._last_cond
+    try:
+        a, b = torch.zeros(1, 4, 6, 6), torch.zeros(1, 4, 3, 3)
+        feats = {1: a, 2: b}
+        fu._last_cond = None
+        assert not fu._cond_unchanged(feats)                      # nothing loaded yet
+        fu._remember_cond(feats)
+        assert fu._cond_unchanged(feats)
+        assert fu._cond_unchanged({1: a, 2: b})                   # another dict of the same tensors
+        assert not fu._cond_unchanged({1: a})                     # another set of levels
+        assert not fu._cond_unchanged({1: a, 2: b.clone()})       # equal values, another object
+        a.add_(1.0)                                               # written in place
+        assert not fu._cond_unchanged(feats)
+        fu._remember_cond(feats)
+        assert fu._cond_unchanged(feats)
+        assert not fu._cond_unchanged({1: a.double(), 2: b})
+        nc = torch.zeros(1, 4, 6, 12)[..., ::2]
+        fu._remember_cond({1: nc, 2: b})
+        assert not fu._cond_unchanged({1: nc, 2: b})              # needs a contiguous copy: never early
+        with torch.inference_mode():
+            inf = torch.zeros(1, 4, 6, 6)
+        fu._remember_cond({1: inf, 2: b})
+        assert not fu._cond_unchanged({1: inf, 2: b})             # no version counter: writes could not be seen
+        c = torch.zeros(1, 4, 6, 6)
+        fu._remember_cond({1: c, 2: b})
+        del c                                                     # the remembered tensor is gone (weak reference)
+        assert not fu._cond_unchanged({1: torch.zeros(1, 4, 6, 6), 2: b})
+        prev = hip.set_cross_pass_overlap(False)
+        assert hip.set_cross_pass_overlap() is False and hip.set_cross_pass_overlap(prev) is False
+        assert hip.set_cross_pass_overlap() == prev
+    finally:
+        fu._last_cond = saved
