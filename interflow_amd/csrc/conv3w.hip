@@ -31,8 +31,33 @@ __device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// torch.sigmoid(h + 2.) + eps and log(scale), on the hardware's exp2 / rcp / log2 with the argument reduction spelled out: the
+// library forms cost ~32 instructions per element (range checks, denormal paths, the IEEE division sequence), 40 % of this
+// kernel's epilogue; these take 11 and stay within ~1 ulp (exp: x log2(e) split as n + r with a two-term log2(e), 2^r by
+// v_exp_f32 on |r| <= 1/2; reciprocal: v_rcp_f32 + one Newton step; log: v_log_f32 x ln 2 on arguments in [eps, 1 + eps]).
+// -DIFL_LIBM_SCALE: the library forms.
 __device__ __forceinline__ float scale_of(float h, float eps) {
-    return 1.0f / (1.0f + expf(-(h + 2.0f))) + eps;                    // torch.sigmoid(h + 2.) + eps
+#ifdef IFL_LIBM_SCALE
+    return 1.0f / (1.0f + expf(-(h + 2.0f))) + eps;
+#else
+    float t = -(h + 2.0f);
+    t = __builtin_fminf(__builtin_fmaxf(t, -87.0f), 88.0f);            // exp(88) is finite; sigmoid is 0 / 1 to the last bit beyond
+    const float n = __builtin_rintf(t * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(t, 1.44269502162933349609375f, -n);
+    r = __builtin_fmaf(t, 1.925963033500011e-8f, r);
+    const float e = __builtin_ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+    const float d = 1.0f + e;
+    const float x0 = __builtin_amdgcn_rcpf(d);
+    const float x1 = __builtin_fmaf(__builtin_fmaf(-d, x0, 1.0f), x0, x0);
+    return x1 + eps;
+#endif
+}
+__device__ __forceinline__ float log_scale(float s) {
+#ifdef IFL_LIBM_SCALE
+    return logf(s);
+#else
+    return __builtin_amdgcn_logf(s) * 0.693147182464599609375f;       // s in [eps, 1 + eps]: no denormals, no specials
+#endif
 }
 
 enum { W3_F = 0, W3_ENC = 1, W3_DEC = 2 };
@@ -231,7 +256,7 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
                     for (int e = 0; e < 2; ++e) {
                         o[2 * e] = (f[e] + bF[e]) * eF[e];                                        // shift
                         o[2 * e + 1] = scale_of((f[2 + e] + bF[2 + e]) * eF[2 + e], eps);           // scale
-                        ld += logf(o[2 * e + 1]);
+                        ld += log_scale(o[2 * e + 1]);
                     }
                     *(f32x4*)(sf + op * (2 * C) + 2 * c) = o;
                 }
@@ -266,11 +291,11 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
                             if (MODE == W3_ENC) {
                                 z[e] = z[e] / sc;
                                 z[e] = z[e] - sh;
-                                ld -= logf(sc);
+                                ld -= log_scale(sc);
                             } else {
                                 z[e] = z[e] + sh;
                                 z[e] = z[e] * sc;
-                                ld += logf(sc);
+                                ld += log_scale(sc);
                             }
                         }
                     }
