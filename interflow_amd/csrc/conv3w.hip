@@ -33,8 +33,8 @@ __device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {
 
 // torch.sigmoid(h + 2.) + eps and log(scale), on the hardware's exp2 / rcp / log2 with the argument reduction spelled out: the
 // library forms cost ~32 instructions per element (range checks, denormal paths, the IEEE division sequence), 40 % of this
-// kernel's epilogue; these take 11 and stay within ~1 ulp (exp: x log2(e) split as n + r with a two-term log2(e), 2^r by
-// v_exp_f32 on |r| <= 1/2; reciprocal: v_rcp_f32 + one Newton step; log: v_log_f32 x ln 2 on arguments in [eps, 1 + eps]).
+// kernel's epilogue; these take 13 and stay within ~1 ulp (exp: x log2(e) split as n + r with a two-term log2(e), 2^r by
+// v_exp_f32 on |r| <= 1/2; reciprocal: v_rcp_f32 + two Newton steps; log: v_log_f32 x ln 2 on arguments in [eps, 1 + eps]).
 // -DIFL_LIBM_SCALE: the library forms.
 __device__ __forceinline__ float scale_of(float h, float eps) {
 #ifdef IFL_LIBM_SCALE
@@ -49,7 +49,8 @@ __device__ __forceinline__ float scale_of(float h, float eps) {
     const float d = 1.0f + e;
     const float x0 = __builtin_amdgcn_rcpf(d);
     const float x1 = __builtin_fmaf(__builtin_fmaf(-d, x0, 1.0f), x0, x0);
-    return x1 + eps;
+    const float x2 = __builtin_fmaf(__builtin_fmaf(-d, x1, 1.0f), x1, x1);      // second step: the quotient to the last bit (as the division)
+    return x2 + eps;
 #endif
 }
 __device__ __forceinline__ float log_scale(float s) {
