@@ -6,7 +6,7 @@
 set -o pipefail
 TAG=${1:-prof}
 shift
-PMC_ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline --no-secondary}
+PMC_ARGS=${*:---steps 4 --warmup 2 --no-cpu-baseline --no-secondary}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p "$O"
