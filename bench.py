@@ -275,6 +275,11 @@ def main():
                                    "K=16 L=2 shipped config, lr_enc precomputed (synthetic 320-channel features), "
                                    "add_gt_noise=False (BASELINE.json configs[1])",
                        "cross_pass_overlap": bool(hip.set_cross_pass_overlap()),
+                       "schedule_note": "every pass loads and converts the conditioning maps and runs all of both coupling networks "
+                                        "(no PreparedCond); with cross_pass_overlap a pass whose conditioning tensors are the previous "
+                                        "pass's, unwritten since, enqueues that work on the library's bulk stream behind the previous "
+                                        "pass's bulk work instead of behind its whole chain (IFL_FLOW_COND_EARLY; bit-identical "
+                                        "outputs; --no-cross-pass-overlap measures the plain order)",
                        "batch_per_gpu": B, "patch": PATCH, "sharding": f"dp{world} (independent batches, no collective)",
                        "world_size": dist.get_world_size() if dist is not None else 1, "ranks": ranks},
             "roofline": {"bound": "mfma",
