@@ -96,7 +96,7 @@ __device__ __forceinline__ s16x4 to_bf16(f32x4 v) {
 // NTW: row tiles per workgroup.  2 (fFeatures at C = 12: both of its tiles): the patch is staged and transformed once for
 // both, 32 accumulators per lane, two workgroups per CU instead of three.
 template <int MODE, bool BF16, int NTW = 1>
-__global__ __launch_bounds__(256, NTW == 1 ? 3 : 2)
+__global__ __launch_bounds__(256, (NTW == 1 && !BF16) ? 3 : 2)        // (bf16: the operand conversions need registers; at 3 workgroups per CU it spilled 230 bytes per lane)
 void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstride, float* sfAll, int64_t sf_step,
                    float* __restrict__ zP, float* __restrict__ ldpart, int ld_slots, int slot0,
                    const float* __restrict__ params, IflStepList steps, int64_t w3w_off, int64_t b3_off, int NT, int NA,
@@ -343,7 +343,7 @@ int ifl_k_conv3w(int mode, const float* src, int64_t src_step, int pstride, floa
     if ((int64_t)(H + 2) * (W + 2) * pstride >= (int64_t)1 << 31) { ifl_set_error("conv3 (Winograd): plane too large for 32-bit offsets"); return IFL_ENOTSUP; }
     // fFeatures, fp32: two row tiles per workgroup (C = 12: both; C = 48: three pairs; IFL_CONV3_F_PAIR=0: one each; +0.7 % and +0.4 %)
     static const int f_pair = [] { const char* e = getenv("IFL_CONV3_F_PAIR"); return e ? atoi(e) : 3; }();     // bit 0: C = 12, bit 1: C = 48
-    const int ntw = (mode == W3_F && !bf16 && NT % 2 == 0 && (f_pair & (NT == 2 ? 1 : 2))) ? 2 : 1;
+    const int ntw = (mode == W3_F && !bf16 && NT % 2 == 0 && (f_pair & (NT == 2 ? 1 : 2))) ? 2 : 1;      // (bf16 with two tiles spills: 4.4 against 3.1 ms)
     dim3 grid(nwg, B, nsteps * (NT / ntw)), block(256);
     const int64_t w3w = off.w3w[mode == W3_F ? 1 : 0], b3 = off.b3[mode == W3_F ? 1 : 0];
 #define IFL_W3_LAUNCH(M, BF, ...) hipLaunchKernelGGL((conv3w_kernel<M, BF, ##__VA_ARGS__>), grid, block, 0, st, src, src_step, pstride, sf, sf_step, z, ldpart, \
