@@ -154,7 +154,10 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
 #pragma unroll
         for (int tw = 0; tw < NTW; ++tw)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *(f32x4*)&us[tw * USZ + (tid + k * 256) * 4] = upre[tw][k];
+            for (int k = 0; k < 4; ++k) {
+                if (BF16) *(s16x4*)((short*)us + tw * USZ + (tid + k * 256) * 4) = to_bf16(upre[tw][k]);      // rounded once here, not by each of the 4 waves that read it
+                else *(f32x4*)&us[tw * USZ + (tid + k * 256) * 4] = upre[tw][k];
+            }
     };
 
     // ---- this lane's tile ----
@@ -192,9 +195,11 @@ void conv3w_kernel(const float* __restrict__ srcAll, int64_t src_step, int pstri
             for (int p = 0; p < 16; ++p)
 #pragma unroll
                 for (int tw = 0; tw < NTW; ++tw) {
-                    const f32x4 a = *(const f32x4*)&us[tw * USZ + abase + p * 256];
-                    if (BF16) accs[tw][p] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16(a), to_bf16(v[p >> 2][p & 3]), accs[tw][p], 0, 0, 0);
-                    else {
+                    if (BF16) {
+                        const s16x4 ab = *(const s16x4*)((const short*)us + tw * USZ + abase + p * 256);
+                        accs[tw][p] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, to_bf16(v[p >> 2][p & 3]), accs[tw][p], 0, 0, 0);
+                    } else {
+                        const f32x4 a = *(const f32x4*)&us[tw * USZ + abase + p * 256];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) accs[tw][p] = mfma16w(a[e], v[p >> 2][p & 3][e], accs[tw][p]);
                     }
